@@ -1,0 +1,700 @@
+// engine.hip -- host side of libblackbird_hip.so: the C ABI of include/blackbird_hip.h.
+// Owns all device memory (hipMalloc), one HIP stream per engine, and the launch sequences:
+//   simulation  = k_tree_step (apply previous leaf: expand+backup; select next leaf)  ->  evaluator kernel
+//   move        = k_selfplay_move (apply last leaf; sample; record example; re-root; game over -> next game)
+#include "../../include/blackbird_hip.h"
+#include "eval.hip.h"
+#include "net.hip.h"
+#include "tree.hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x)                                                                                      \
+    do {                                                                                               \
+        hipError_t _e = (x);                                                                           \
+        if (_e != hipSuccess) return fail(BB_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), \
+                                          __FILE__, __LINE__);                                         \
+    } while (0)
+
+extern "C" const char *bb_last_error(void) { return g_err.c_str(); }
+
+extern "C" int bb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+template <class G>
+static void fill_info(bb_game_info *o) {
+    o->H = G::H;
+    o->W = G::W;
+    o->C = G::C;
+    o->A = G::A;
+    o->S = G::S;
+    o->state_bytes = (int)sizeof(typename G::State);
+    o->dense = 1;
+    o->example_bytes = (int)(sizeof(ExampleHdr) + sizeof(typename G::State) + 4 * G::S);
+}
+
+extern "C" int bb_game_info_get(int game, bb_game_info *out) {
+    if (!out) return fail(BB_ERR_ARG, "null out");
+    switch (game) {
+    case BB_GAME_CONNECT4: fill_info<Connect4>(out); return BB_OK;
+    case BB_GAME_TICTACTOE: fill_info<TicTacToe>(out); return BB_OK;
+    default: return fail(BB_ERR_ARG, "unknown or unsupported game %d", game);
+    }
+}
+
+// ---- device scratch with automatic release ---------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        return e == hipSuccess ? 0 : fail(BB_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+};
+
+static inline int nblk(size_t n, int per = 256) { return (int)((n + per - 1) / per); }
+
+// ---- stateless batched game ops ------------------------------------------------------------------
+template <class G>
+static int game_legal(int n, const void *states, uint8_t *out) {
+    DevBuf ds, dout;
+    if (ds.alloc((size_t)n * sizeof(typename G::State)) || dout.alloc((size_t)n * G::A)) return BB_ERR_HIP;
+    HIPCHK(hipMemcpy(ds.p, states, (size_t)n * sizeof(typename G::State), hipMemcpyDefault));
+    k_game_legal<G><<<nblk(n), 256>>>(n, (const typename G::State *)ds.p, (uint8_t *)dout.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dout.p, (size_t)n * G::A, hipMemcpyDefault));
+    return BB_OK;
+}
+template <class G>
+static int game_apply(int n, void *states, const int32_t *actions, int32_t *status) {
+    DevBuf ds, da, dst;
+    if (ds.alloc((size_t)n * sizeof(typename G::State)) || da.alloc((size_t)n * 4) || dst.alloc((size_t)n * 4))
+        return BB_ERR_HIP;
+    HIPCHK(hipMemcpy(ds.p, states, (size_t)n * sizeof(typename G::State), hipMemcpyDefault));
+    HIPCHK(hipMemcpy(da.p, actions, (size_t)n * 4, hipMemcpyDefault));
+    k_game_apply<G><<<nblk(n), 256>>>(n, (typename G::State *)ds.p, (const int32_t *)da.p, (int32_t *)dst.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(states, ds.p, (size_t)n * sizeof(typename G::State), hipMemcpyDefault));
+    if (status) HIPCHK(hipMemcpy(status, dst.p, (size_t)n * 4, hipMemcpyDefault));
+    return BB_OK;
+}
+template <class G>
+static int game_winner(int n, const void *states, const int32_t *prev, int8_t *out) {
+    DevBuf ds, dp, dout;
+    if (ds.alloc((size_t)n * sizeof(typename G::State)) || dp.alloc((size_t)n * 4) || dout.alloc((size_t)n))
+        return BB_ERR_HIP;
+    HIPCHK(hipMemcpy(ds.p, states, (size_t)n * sizeof(typename G::State), hipMemcpyDefault));
+    if (prev) HIPCHK(hipMemcpy(dp.p, prev, (size_t)n * 4, hipMemcpyDefault));
+    k_game_winner<G><<<nblk(n), 256>>>(n, (const typename G::State *)ds.p, prev ? (const int32_t *)dp.p : nullptr,
+                                       (int8_t *)dout.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dout.p, (size_t)n, hipMemcpyDefault));
+    return BB_OK;
+}
+template <class G>
+static int game_encode(int n, const void *states, int8_t *out) {
+    size_t ob = (size_t)n * G::H * G::W * G::C;
+    DevBuf ds, dout;
+    if (ds.alloc((size_t)n * sizeof(typename G::State)) || dout.alloc(ob)) return BB_ERR_HIP;
+    HIPCHK(hipMemcpy(ds.p, states, (size_t)n * sizeof(typename G::State), hipMemcpyDefault));
+    k_game_encode<G><<<nblk((size_t)n * G::H * G::W), 256>>>(n, (const typename G::State *)ds.p, (int8_t *)dout.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dout.p, ob, hipMemcpyDefault));
+    return BB_OK;
+}
+
+#define GAME_SWITCH(game, ...)                                                   \
+    switch (game) {                                                              \
+    case BB_GAME_CONNECT4: { using G = Connect4; __VA_ARGS__; }                  \
+    case BB_GAME_TICTACTOE: { using G = TicTacToe; __VA_ARGS__; }                \
+    default: return fail(BB_ERR_ARG, "unknown or unsupported game %d", game);    \
+    }
+
+extern "C" int bb_game_legal(int game, int n, const void *states, uint8_t *legal_out) {
+    if (n <= 0 || !states || !legal_out) return fail(BB_ERR_ARG, "bad arguments");
+    GAME_SWITCH(game, return game_legal<G>(n, states, legal_out));
+}
+extern "C" int bb_game_apply(int game, int n, void *states, const int32_t *actions, int32_t *status_out) {
+    if (n <= 0 || !states || !actions) return fail(BB_ERR_ARG, "bad arguments");
+    GAME_SWITCH(game, return game_apply<G>(n, states, actions, status_out));
+}
+extern "C" int bb_game_winner(int game, int n, const void *states, const int32_t *prev, int8_t *winner_out) {
+    if (n <= 0 || !states || !winner_out) return fail(BB_ERR_ARG, "bad arguments");
+    GAME_SWITCH(game, return game_winner<G>(n, states, prev, winner_out));
+}
+extern "C" int bb_game_encode(int game, int n, const void *states, int8_t *planes_out) {
+    if (n <= 0 || !states || !planes_out) return fail(BB_ERR_ARG, "bad arguments");
+    GAME_SWITCH(game, return game_encode<G>(n, states, planes_out));
+}
+extern "C" int bb_game_initial(int game, void *state_out) {
+    if (!state_out) return fail(BB_ERR_ARG, "null out");
+    GAME_SWITCH(game, {
+        typename G::State s = G::initial();
+        memcpy(state_out, &s, sizeof s);
+        return BB_OK;
+    });
+}
+
+// ---- engine ----------------------------------------------------------------------------------------
+struct bb_engine {
+    bb_config cfg;
+    bb_game_info info;
+    TreeDev dev;
+    NetDev net;
+    bool has_weights = false;
+    int net_F = 0, net_C = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    int n_games_target = 0;
+    size_t node_bytes = 0;
+    double *d_u = nullptr;
+    int32_t *d_actions = nullptr;
+};
+
+template <class T>
+static int dalloc(bb_engine *e, T *&p, size_t count, bool zero = true) {
+    void *q = nullptr;
+    size_t bytes = count * sizeof(T);
+    hipError_t err = hipMalloc(&q, bytes ? bytes : 16);
+    if (err != hipSuccess) return fail(BB_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+    e->allocs.push_back(q);
+    if (zero && bytes) {
+        err = hipMemsetAsync(q, 0, bytes, e->stream);
+        if (err != hipSuccess) return fail(BB_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(err));
+    }
+    p = (T *)q;
+    return 0;
+}
+
+template <class G>
+static int engine_alloc(bb_engine *e) {
+    TreeDev &d = e->dev;
+    const bb_config &c = e->cfg;
+    size_t n = (size_t)c.n_slots;
+    e->node_bytes = sizeof(DenseNode<G>);
+    if (dalloc(e, d.root, n) || dalloc(e, d.root_N, n) || dalloc(e, d.n_nodes, n) || dalloc(e, d.ply, n) ||
+        dalloc(e, d.sims_left, n) || dalloc(e, d.pend_leaf, n) || dalloc(e, d.pend_expand, n) ||
+        dalloc(e, d.path_len, n) || dalloc(e, d.game_lid, n) || dalloc(e, d.sim_serial, n) ||
+        dalloc(e, d.root_W, n) || dalloc(e, d.root_pp, n) || dalloc(e, d.path, n * G::MAXPATH) ||
+        dalloc(e, d.leaf_game_id, n) || dalloc(e, d.leaf_serial, n) || dalloc(e, d.eval_value, n) ||
+        dalloc(e, d.eval_policy, n * G::S) || dalloc(e, d.ctr, n * 8) || dalloc(e, d.out_action, n) ||
+        dalloc(e, d.out_root_plays, n) || dalloc(e, d.out_child_plays, n * G::S) ||
+        dalloc(e, d.out_root_winrate, n) || dalloc(e, d.out_child_value, n * G::S) || dalloc(e, e->d_u, n) ||
+        dalloc(e, e->d_actions, n))
+        return BB_ERR_HIP;
+    typename G::State *ls;
+    if (dalloc(e, ls, n)) return BB_ERR_HIP;
+    d.leaf_state = ls;
+    uint8_t *nodes;
+    if (dalloc(e, nodes, n * (size_t)d.node_cap * sizeof(DenseNode<G>), false)) return BB_ERR_HIP;
+    d.nodes = nodes;
+    size_t ng = (size_t)c.max_games;
+    if (dalloc(e, d.examples, ng * (size_t)(c.max_plies + 1) * (size_t)e->info.example_bytes, false) ||
+        dalloc(e, d.game_hdr, ng * 4))
+        return BB_ERR_HIP;
+    // every slot idle until roots are set / self-play begins
+    HIPCHK(hipMemsetAsync(d.game_lid, 0xFF, n * 4, e->stream));
+    HIPCHK(hipMemsetAsync(d.pend_leaf, 0xFF, n * 4, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return BB_OK;
+}
+
+extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
+    if (!cfg || !out) return fail(BB_ERR_ARG, "null argument");
+    if (cfg->n_slots <= 0) return fail(BB_ERR_ARG, "n_slots must be positive");
+    if (cfg->mcts_kind == BB_MCTS_FIXED && cfg->max_depth <= 0)
+        return fail(BB_ERR_ARG, "MaxDepth for MCTS must be > 0."); // FixedMCTS.py:15-16
+    if (cfg->sims_per_move < 0 || cfg->max_plies <= 0) return fail(BB_ERR_ARG, "bad sims_per_move/max_plies");
+    int ndev = bb_device_count();
+    if (ndev <= 0) return fail(BB_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(BB_ERR_ARG, "device %d out of range", cfg->device);
+    bb_engine *e = new bb_engine();
+    e->cfg = *cfg;
+    int rc = bb_game_info_get(cfg->game, &e->info);
+    if (rc) {
+        delete e;
+        return rc;
+    }
+    HIPCHK(hipSetDevice(cfg->device));
+    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    TreeDev &d = e->dev;
+    memset(&d, 0, sizeof d);
+    d.n_slots = cfg->n_slots;
+    d.sims_per_move = cfg->sims_per_move;
+    d.max_plies = cfg->max_plies;
+    d.kind = cfg->mcts_kind;
+    d.max_depth = cfg->max_depth;
+    d.evaluator = cfg->evaluator;
+    d.priors_ones = (cfg->mcts_kind == BB_MCTS_FIXED || cfg->evaluator == BB_EVAL_ROLLOUT) ? 1 : 0;
+    d.salt_per_game = cfg->salt_per_game;
+    d.max_games = cfg->max_games > 0 ? cfg->max_games : cfg->n_slots;
+    e->cfg.max_games = d.max_games;
+    d.c_puct = cfg->c_puct;
+    d.seed = cfg->seed;
+    d.salt = cfg->hash_salt;
+    d.first_game_id = cfg->first_game_id;
+    long cap = cfg->node_capacity > 0 ? cfg->node_capacity : (long)cfg->sims_per_move * cfg->max_plies + 2;
+    if (cfg->mcts_kind == BB_MCTS_FIXED && cfg->node_capacity <= 0) cap = cap * cfg->max_depth;
+    if (cap >= (1 << 26)) return fail(BB_ERR_ARG, "node capacity too large");
+    d.node_cap = (int)cap;
+    d.example_bytes = e->info.example_bytes;
+    d.temp = 1.0;
+    GAME_SWITCH(cfg->game, rc = engine_alloc<G>(e); break);
+    if (rc) {
+        bb_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return BB_OK;
+}
+
+extern "C" int bb_destroy(bb_engine *e) {
+    if (!e) return BB_OK;
+    (void)hipSetDevice(e->cfg.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void *p : e->allocs) (void)hipFree(p);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return BB_OK;
+}
+
+extern "C" int bb_synchronize(bb_engine *e) {
+    if (!e) return fail(BB_ERR_ARG, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return BB_OK;
+}
+
+// ---- weights: fold BN, swizzle into MFMA operand order, upload ---------------------------------------
+static void bn_fold(const float *bn, int F, float *scale, float *shift) {
+    for (int f = 0; f < F; f++) {
+        float g = bn[0 * F + f], b = bn[1 * F + f], m = bn[2 * F + f], v = bn[3 * F + f];
+        float s = g / sqrtf(v + 1e-3f); // tf.layers.batch_normalization default epsilon
+        float t = m * s;
+        scale[f] = s;
+        shift[f] = b - t;
+    }
+}
+
+extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
+    if (!e || !w) return fail(BB_ERR_ARG, "null argument");
+    const bb_game_info &gi = e->info;
+    if (w->H != gi.H || w->W != gi.W || w->C != gi.C || w->A != gi.A)
+        return fail(BB_ERR_ARG, "weights are for a %dx%dx%d/%d network, game needs %dx%dx%d/%d", w->H, w->W, w->C,
+                    w->A, gi.H, gi.W, gi.C, gi.A);
+    if (w->F != 16) return fail(BB_ERR_ARG, "this build carries the fused F=16 tower only (got filters=%d)", w->F);
+    if (w->D <= 0 || w->D > 64 || w->R < 0) return fail(BB_ERR_ARG, "unsupported dense/blocks");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const int F = 16, C = w->C, R = w->R, D = w->D, A = w->A;
+    const int steps0 = (9 * C + 3) / 4;
+    std::vector<float> w0((size_t)steps0 * 64), wt((size_t)2 * R * 9 * 64 * 4), epi((size_t)(1 + 2 * R) * 48);
+    for (int s = 0; s < steps0; s++)
+        for (int lane = 0; lane < 64; lane++) {
+            int f = lane & 15, j = lane >> 4, k = 4 * s + j;
+            w0[(size_t)s * 64 + lane] = k < 9 * C ? w->conv0_k[(size_t)k * F + f] : 0.f;
+        }
+    for (int l = 0; l < 2 * R; l++)
+        for (int tap = 0; tap < 9; tap++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int r = 0; r < 4; r++) {
+                    int f = lane & 15, j = lane >> 4, c = 4 * j + r;
+                    wt[(((size_t)l * 9 + tap) * 64 + lane) * 4 + r] = w->blk_k[(((size_t)l * 9 + tap) * F + c) * F + f];
+                }
+    for (int l = 0; l < 1 + 2 * R; l++) {
+        const float *b = l == 0 ? w->conv0_b : w->blk_b + (size_t)(l - 1) * F;
+        const float *bn = l == 0 ? w->conv0_bn : w->blk_bn + (size_t)(l - 1) * 4 * F;
+        memcpy(&epi[(size_t)l * 48], b, F * sizeof(float));
+        bn_fold(bn, F, &epi[(size_t)l * 48 + 16], &epi[(size_t)l * 48 + 32]);
+    }
+    std::vector<float> head;
+    NetDev &nd = e->net;
+    auto push = [&](const float *p, int n) {
+        int off = (int)head.size();
+        head.insert(head.end(), p, p + n);
+        while (head.size() % 4) head.push_back(0.f);
+        return off;
+    };
+    float v3[3], p6[6], s1, t1, s2[2], t2[2];
+    bn_fold(w->v_bn, 1, &s1, &t1);
+    bn_fold(w->p_bn, 2, s2, t2);
+    v3[0] = w->v_conv_b[0]; v3[1] = s1; v3[2] = t1;
+    p6[0] = w->p_conv_b[0]; p6[1] = w->p_conv_b[1]; p6[2] = s2[0]; p6[3] = s2[1]; p6[4] = t2[0]; p6[5] = t2[1];
+    nd.off_vk = push(w->v_conv_k, F);
+    nd.off_v3 = push(v3, 3);
+    nd.off_d1k = push(w->v_d1_k, D);
+    nd.off_d1b = push(w->v_d1_b, D);
+    nd.off_d2k = push(w->v_d2_k, D);
+    nd.off_d2b = push(w->v_d2_b, 1);
+    nd.off_pk = push(w->p_conv_k, 2 * F);
+    nd.off_p6 = push(p6, 6);
+    nd.off_pdk = push(w->p_d_k, 2 * A);
+    nd.off_pdb = push(w->p_d_b, A);
+    float *d_w0, *d_wt, *d_epi, *d_head;
+    if (dalloc(e, d_w0, w0.size(), false) || dalloc(e, d_wt, wt.size(), false) || dalloc(e, d_epi, epi.size(), false) ||
+        dalloc(e, d_head, head.size(), false))
+        return BB_ERR_HIP;
+    HIPCHK(hipMemcpy(d_w0, w0.data(), w0.size() * 4, hipMemcpyHostToDevice));
+    if (!wt.empty()) HIPCHK(hipMemcpy(d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_epi, epi.data(), epi.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_head, head.data(), head.size() * 4, hipMemcpyHostToDevice));
+    nd.R = R;
+    nd.D = D;
+    nd.A = A;
+    nd.w0 = d_w0;
+    nd.wt = (const f32x4 *)d_wt;
+    nd.epi = d_epi;
+    nd.head = d_head;
+    nd.seed = e->cfg.seed;
+    nd.alpha = e->cfg.alpha;
+    nd.eps = e->cfg.epsilon;
+    e->has_weights = true;
+    e->net_F = F;
+    e->net_C = C;
+    return BB_OK;
+}
+
+// positions per wave of the fused tower, chosen so that 4 waves' activations fill the 160 KiB LDS
+template <class G> struct NetPW;
+template <> struct NetPW<Connect4> { static constexpr int v = 4; };
+template <> struct NetPW<TicTacToe> { static constexpr int v = 12; };
+
+template <class G>
+static int launch_net(bb_engine *e, int n, const typename G::State *states, const int8_t *planes,
+                      const uint32_t *game_id, const int32_t *serial, int noise, float *value, float *logits,
+                      float *policy, int pstride, hipStream_t st) {
+    constexpr int PW = NetPW<G>::v;
+    int blocks = (n + 4 * PW - 1) / (4 * PW);
+    k_net_fused16<G, PW><<<blocks, 256, 0, st>>>(e->net, n, states, planes, game_id, serial, noise, value, logits,
+                                                  policy, pstride);
+    HIPCHK(hipGetLastError());
+    return BB_OK;
+}
+
+template <class G>
+static int net_eval(bb_engine *e, int n, const void *states, const int8_t *planes, float *value, float *logits,
+                    float *policy, int noise) {
+    const int A = G::A;
+    size_t pb = (size_t)n * G::H * G::W * G::C;
+    DevBuf din, dv, dl, dp;
+    if (din.alloc(states ? (size_t)n * sizeof(typename G::State) : pb) || dv.alloc((size_t)n * 4) ||
+        dl.alloc((size_t)n * A * 4) || dp.alloc((size_t)n * A * 4))
+        return BB_ERR_HIP;
+    HIPCHK(hipMemcpy(din.p, states ? states : (const void *)planes, states ? (size_t)n * sizeof(typename G::State) : pb,
+                     hipMemcpyDefault));
+    int rc = launch_net<G>(e, n, states ? (const typename G::State *)din.p : nullptr,
+                           states ? nullptr : (const int8_t *)din.p, nullptr, nullptr, noise, (float *)dv.p,
+                           (float *)dl.p, (float *)dp.p, A, e->stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (value) HIPCHK(hipMemcpy(value, dv.p, (size_t)n * 4, hipMemcpyDefault));
+    if (logits) HIPCHK(hipMemcpy(logits, dl.p, (size_t)n * A * 4, hipMemcpyDefault));
+    if (policy) HIPCHK(hipMemcpy(policy, dp.p, (size_t)n * A * 4, hipMemcpyDefault));
+    return BB_OK;
+}
+
+extern "C" int bb_net_eval(bb_engine *e, int n, const void *states, const int8_t *planes, float *value_out,
+                           float *logits_out, float *policy_out, int noise) {
+    if (!e || n <= 0 || (!states == !planes)) return fail(BB_ERR_ARG, "bad arguments (exactly one of states/planes)");
+    if (!e->has_weights) return fail(BB_ERR_WEIGHTS, "bb_load_weights has not been called");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    GAME_SWITCH(e->cfg.game, return net_eval<G>(e, n, states, planes, value_out, logits_out, policy_out, noise));
+}
+
+template <class G>
+static int hash_eval(bb_engine *e, int n, const void *states, float *value, float *policy) {
+    DevBuf ds, dv, dp;
+    if (ds.alloc((size_t)n * sizeof(typename G::State)) || dv.alloc((size_t)n * 4) || dp.alloc((size_t)n * G::A * 4))
+        return BB_ERR_HIP;
+    HIPCHK(hipMemcpy(ds.p, states, (size_t)n * sizeof(typename G::State), hipMemcpyDefault));
+    k_hash_eval<G><<<nblk(n), 256, 0, e->stream>>>(n, (const typename G::State *)ds.p, nullptr, e->cfg.hash_salt, 0, 0,
+                                                   (float *)dv.p, (float *)dp.p, G::A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (value) HIPCHK(hipMemcpy(value, dv.p, (size_t)n * 4, hipMemcpyDefault));
+    if (policy) HIPCHK(hipMemcpy(policy, dp.p, (size_t)n * G::A * 4, hipMemcpyDefault));
+    return BB_OK;
+}
+
+extern "C" int bb_hash_eval(bb_engine *e, int n, const void *states, float *value_out, float *policy_out) {
+    if (!e || n <= 0 || !states) return fail(BB_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    GAME_SWITCH(e->cfg.game, return hash_eval<G>(e, n, states, value_out, policy_out));
+}
+
+// ---- simulation loop ---------------------------------------------------------------------------------
+template <class G>
+static int launch_eval(bb_engine *e) {
+    TreeDev &d = e->dev;
+    int n = d.n_slots;
+    const typename G::State *ls = (const typename G::State *)d.leaf_state;
+    switch (d.evaluator) {
+    case BB_EVAL_HASH:
+        k_hash_eval<G><<<nblk(n), 256, 0, e->stream>>>(n, ls, d.leaf_game_id, d.salt, d.salt_per_game, d.first_game_id,
+                                                       d.eval_value, d.eval_policy, G::S);
+        break;
+    case BB_EVAL_NET:
+        return launch_net<G>(e, n, ls, nullptr, d.leaf_game_id, d.leaf_serial, e->cfg.noise_on, d.eval_value, nullptr,
+                             d.eval_policy, G::S, e->stream);
+    case BB_EVAL_ROLLOUT:
+        k_rollout<G><<<nblk(n), 256, 0, e->stream>>>(n, ls, d.leaf_game_id, d.sim_serial, d.pend_leaf, d.seed,
+                                                     d.eval_value);
+        break;
+    default: return fail(BB_ERR_ARG, "unknown evaluator %d", d.evaluator);
+    }
+    HIPCHK(hipGetLastError());
+    return BB_OK;
+}
+
+template <class G>
+static int run_sims(bb_engine *e, int sims) {
+    TreeDev &d = e->dev;
+    int tb = nblk((size_t)d.n_slots * G::S);
+    for (int s = 0; s < sims; s++) {
+        k_tree_step<G><<<tb, 256, 0, e->stream>>>(d);
+        HIPCHK(hipGetLastError());
+        int rc = launch_eval<G>(e);
+        if (rc) return rc;
+    }
+    return BB_OK;
+}
+
+static int check_eval(bb_engine *e) {
+    if (e->cfg.evaluator == BB_EVAL_NET && !e->has_weights)
+        return fail(BB_ERR_WEIGHTS, "network evaluator needs bb_load_weights first");
+    return BB_OK;
+}
+
+template <class G>
+static int set_roots(bb_engine *e, int n, const int32_t *slots, const void *states, const uint32_t *gids) {
+    DevBuf ds, dsl, dg;
+    if (ds.alloc((size_t)n * sizeof(typename G::State)) || dsl.alloc((size_t)n * 4) || dg.alloc((size_t)n * 4))
+        return BB_ERR_HIP;
+    HIPCHK(hipMemcpy(ds.p, states, (size_t)n * sizeof(typename G::State), hipMemcpyDefault));
+    if (slots) HIPCHK(hipMemcpy(dsl.p, slots, (size_t)n * 4, hipMemcpyDefault));
+    if (gids) HIPCHK(hipMemcpy(dg.p, gids, (size_t)n * 4, hipMemcpyDefault));
+    k_set_roots<G><<<nblk(n), 256, 0, e->stream>>>(e->dev, n, slots ? (const int32_t *)dsl.p : nullptr,
+                                                   (const typename G::State *)ds.p, gids ? (const uint32_t *)dg.p : nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return BB_OK;
+}
+
+extern "C" int bb_set_roots(bb_engine *e, int n, const int32_t *slots, const void *states, const uint32_t *game_ids) {
+    if (!e || n <= 0 || n > e->cfg.n_slots || !states) return fail(BB_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    GAME_SWITCH(e->cfg.game, return set_roots<G>(e, n, slots, states, game_ids));
+}
+
+extern "C" int bb_run_sims(bb_engine *e, int sims) {
+    if (!e || sims <= 0) return fail(BB_ERR_ARG, "Not enough information to decide a stop time."); // MCTS.py:181-182
+    int rc = check_eval(e);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    GAME_SWITCH(e->cfg.game, {
+        k_add_sims<G><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, sims);
+        rc = run_sims<G>(e, sims);
+        if (rc) return rc;
+        k_tree_apply<G><<<nblk((size_t)e->dev.n_slots * G::S), 256, 0, e->stream>>>(e->dev);
+        HIPCHK(hipGetLastError());
+        return BB_OK;
+    });
+}
+
+template <class G>
+static int sample_moves(bb_engine *e, double temp, const double *u, int32_t *action, float *wr, int32_t *rp,
+                        int32_t *cact, int32_t *cplays, float *cval) {
+    TreeDev d = e->dev;
+    size_t n = (size_t)d.n_slots;
+    if (u) {
+        HIPCHK(hipMemcpyAsync(e->d_u, u, n * 8, hipMemcpyDefault, e->stream));
+        d.in_u = e->d_u;
+    } else {
+        d.in_u = nullptr;
+    }
+    k_sample<G><<<nblk(n * G::S), 256, 0, e->stream>>>(d, temp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (action) HIPCHK(hipMemcpy(action, d.out_action, n * 4, hipMemcpyDefault));
+    if (wr) HIPCHK(hipMemcpy(wr, d.out_root_winrate, n * 4, hipMemcpyDefault));
+    if (rp) HIPCHK(hipMemcpy(rp, d.out_root_plays, n * 4, hipMemcpyDefault));
+    if (cplays) HIPCHK(hipMemcpy(cplays, d.out_child_plays, n * G::S * 4, hipMemcpyDefault));
+    if (cval) HIPCHK(hipMemcpy(cval, d.out_child_value, n * G::S * 4, hipMemcpyDefault));
+    if (cact) { // dense games: slot i is action i
+        std::vector<int32_t> ca(n * G::S);
+        for (size_t g = 0; g < n; g++)
+            for (int i = 0; i < G::S; i++) ca[g * G::S + i] = i < G::A ? i : -1;
+        HIPCHK(hipMemcpy(cact, ca.data(), ca.size() * 4, hipMemcpyDefault));
+    }
+    return BB_OK;
+}
+
+extern "C" int bb_sample_moves(bb_engine *e, double temp, const double *u, int32_t *action_out,
+                               float *root_winrate_out, int32_t *root_plays_out, int32_t *child_action_out,
+                               int32_t *child_plays_out, float *child_value_out) {
+    if (!e || temp < 0) return fail(BB_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    GAME_SWITCH(e->cfg.game, return sample_moves<G>(e, temp, u, action_out, root_winrate_out, root_plays_out,
+                                                    child_action_out, child_plays_out, child_value_out));
+}
+
+extern "C" int bb_move_roots(bb_engine *e, const int32_t *actions) {
+    if (!e || !actions) return fail(BB_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipMemcpyAsync(e->d_actions, actions, (size_t)e->dev.n_slots * 4, hipMemcpyDefault, e->stream));
+    GAME_SWITCH(e->cfg.game, {
+        k_move_roots<G><<<nblk((size_t)e->dev.n_slots * G::S), 256, 0, e->stream>>>(e->dev, e->d_actions);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return BB_OK;
+    });
+}
+
+extern "C" int bb_get_root_states(bb_engine *e, void *states_out) {
+    if (!e || !states_out) return fail(BB_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    GAME_SWITCH(e->cfg.game, {
+        DevBuf ds;
+        size_t bytes = (size_t)e->dev.n_slots * sizeof(typename G::State);
+        if (ds.alloc(bytes)) return BB_ERR_HIP;
+        k_get_roots<G><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, (typename G::State *)ds.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpy(states_out, ds.p, bytes, hipMemcpyDefault));
+        return BB_OK;
+    });
+}
+
+// ---- self-play ----------------------------------------------------------------------------------------
+extern "C" int bb_selfplay_begin(bb_engine *e, int n_games, double temp) {
+    if (!e) return fail(BB_ERR_ARG, "null engine");
+    if (n_games <= 0) return fail(BB_ERR_ARG, "Use a positive integer for number of games."); // Blackbird.py:235-236
+    if (n_games > e->cfg.max_games)
+        return fail(BB_ERR_CAPACITY, "n_games %d exceeds the engine's max_games %d", n_games, e->cfg.max_games);
+    if (e->cfg.sims_per_move < 2 && temp != 0.0)
+        return fail(BB_ERR_NAN, "probabilities contain NaN (a fresh root needs >= 2 simulations, MCTS.py:336-338)");
+    int rc = check_eval(e);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    e->n_games_target = n_games;
+    e->dev.n_games_target = n_games;
+    e->dev.temp = temp;
+    HIPCHK(hipMemsetAsync(e->dev.game_hdr, 0, (size_t)e->cfg.max_games * 16, e->stream));
+    GAME_SWITCH(e->cfg.game, {
+        k_selfplay_begin<G><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev);
+        HIPCHK(hipGetLastError());
+        return BB_OK;
+    });
+}
+
+extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
+    if (!e || plies <= 0) return fail(BB_ERR_ARG, "bad arguments");
+    if (e->n_games_target <= 0) return fail(BB_ERR_ARG, "bb_selfplay_begin has not been called");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    GAME_SWITCH(e->cfg.game, {
+        for (int p = 0; p < plies; p++) {
+            int rc = run_sims<G>(e, e->cfg.sims_per_move);
+            if (rc) return rc;
+            k_selfplay_move<G><<<nblk((size_t)e->dev.n_slots * G::S), 256, 0, e->stream>>>(e->dev);
+            HIPCHK(hipGetLastError());
+        }
+        return BB_OK;
+    });
+}
+
+static int sum_counters(bb_engine *e, bb_counters *out) {
+    size_t n = (size_t)e->dev.n_slots * 8;
+    std::vector<uint64_t> h(n);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(h.data(), e->dev.ctr, n * 8, hipMemcpyDeviceToHost));
+    uint64_t t[8] = {0};
+    for (size_t i = 0; i < n; i++) t[i & 7] += h[i];
+    out->sims = t[0];
+    out->sum_depth = t[1];
+    out->nodes = t[2];
+    out->terminal_leaves = t[3];
+    out->games_finished = t[4];
+    out->plies = t[5];
+    out->overflow = t[6];
+    out->examples = t[7];
+    return BB_OK;
+}
+
+extern "C" int bb_get_counters(bb_engine *e, bb_counters *out) {
+    if (!e || !out) return fail(BB_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    return sum_counters(e, out);
+}
+
+extern "C" int bb_reset_counters(bb_engine *e) {
+    if (!e) return fail(BB_ERR_ARG, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipMemsetAsync(e->dev.ctr, 0, (size_t)e->dev.n_slots * 64, e->stream));
+    return BB_OK;
+}
+
+extern "C" int bb_selfplay_done(bb_engine *e, int *done_out, int *games_finished_out) {
+    if (!e) return fail(BB_ERR_ARG, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int ng = e->n_games_target;
+    std::vector<int32_t> h((size_t)ng * 4);
+    if (ng) HIPCHK(hipMemcpy(h.data(), e->dev.game_hdr, h.size() * 4, hipMemcpyDeviceToHost));
+    int fin = 0;
+    for (int g = 0; g < ng; g++) fin += h[(size_t)g * 4 + 3] != 0;
+    if (done_out) *done_out = (ng > 0 && fin == ng) ? 1 : 0;
+    if (games_finished_out) *games_finished_out = fin;
+    return BB_OK;
+}
+
+extern "C" int bb_examples_fetch(bb_engine *e, int first_game, int n_games, void *records_out, int max_records,
+                                 int32_t *game_offsets_out, int8_t *winner_out) {
+    if (!e || first_game < 0 || n_games <= 0 || first_game + n_games > e->cfg.max_games || !records_out)
+        return fail(BB_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t eb = (size_t)e->info.example_bytes, per = (size_t)(e->cfg.max_plies + 1) * eb;
+    std::vector<int32_t> hdr((size_t)n_games * 4);
+    HIPCHK(hipMemcpy(hdr.data(), e->dev.game_hdr + (size_t)first_game * 4, hdr.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> stage((size_t)n_games * per);
+    HIPCHK(hipMemcpy(stage.data(), e->dev.examples + (size_t)first_game * per, stage.size(), hipMemcpyDeviceToHost));
+    int total = 0;
+    uint8_t *out = (uint8_t *)records_out;
+    for (int g = 0; g < n_games; g++) {
+        if (game_offsets_out) game_offsets_out[g] = total;
+        int done = hdr[(size_t)g * 4 + 3], nex = hdr[(size_t)g * 4 + 0];
+        if (winner_out) winner_out[g] = done ? (int8_t)hdr[(size_t)g * 4 + 1] : (int8_t)-2;
+        if (!done) continue;
+        if (total + nex > max_records) return fail(BB_ERR_CAPACITY, "records_out too small");
+        memcpy(out + (size_t)total * eb, stage.data() + (size_t)g * per, (size_t)nex * eb);
+        total += nex;
+    }
+    if (game_offsets_out) game_offsets_out[n_games] = total;
+    return total;
+}
+
+extern "C" int bb_examples_device(bb_engine *e, void **ptr_out, uint64_t *bytes_out, uint64_t *record_bytes_out) {
+    if (!e) return fail(BB_ERR_ARG, "null engine");
+    if (ptr_out) *ptr_out = e->dev.examples;
+    if (bytes_out) *bytes_out = (uint64_t)e->cfg.max_games * (uint64_t)(e->cfg.max_plies + 1) * (uint64_t)e->info.example_bytes;
+    if (record_bytes_out) *record_bytes_out = (uint64_t)e->info.example_bytes;
+    return BB_OK;
+}

@@ -1,0 +1,258 @@
+// net.hip.h -- the residual tower + policy/value heads as ONE fused gfx950 kernel (F = 16 filters).
+//
+// Computes what Network.getEvaluation/getPolicy return for the graph NetworkFactory.__call__
+// builds (/root/reference/src/NetworkFactory.py:22-183): conv3x3+bias -> BN -> ReLU,
+// R residual blocks, 1x1 value/policy convs, per-pixel dense + spatial sum, tanh / softmax
+// (+ Beta-noise mix, :176-182).  float32 throughout.
+//
+// Mapping to CDNA4:
+//  * each WAVE owns PW whole positions; their activations ([pixel][16 ch], zero halo) never leave
+//    LDS between layers, so HBM sees only the 16-byte packed boards and the outputs.
+//    One 256-thread workgroup = 4 waves = 4*PW positions (Connect4: 16) -> 4096 positions are
+//    exactly one workgroup per CU.  No __syncthreads(): waves share nothing.
+//  * a 3x3 conv is an implicit GEMM on v_mfma_f32_16x16x4_f32:  D[f][pixel] += W[f][k] * X[k][pixel]
+//    with M = 16 output channels, N = 16 pixels, K = 9*Cin.  Lane (j = lane>>4, n = lane&15) supplies
+//    X for pixel n, channels 4j..4j+3 of one tap with ONE ds_read_b128, and the accumulator lane
+//    layout (4 consecutive channels of one pixel) is exactly what the next layer reads, so the
+//    epilogue (bias-initialised accumulator, BN scale/shift, skip add, ReLU) ends in one ds_write_b128.
+//  * the f32 MFMA is a k-ordered fmaf chain, so results are bit-identical to the CPU oracle's
+//    fmaf chains (same k order) up to expf/tanhf/powf in the heads.
+//  * layer weights (9.2 KB each) stream from L2 into 36 VGPRs per layer, pre-swizzled on the host
+//    into the lane order the MFMA A-operand wants.
+#pragma once
+#include "games.hip.h"
+#include "rng.hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct NetDev {
+    int R, D, A;             // blocks, value dense width, actions
+    const float *w0;         // [steps0][64]            first conv, A-operand lane order
+    const f32x4 *wt;         // [2R][9][64]             tower convs: lane (f=l&15, j=l>>4), .r = W[tap][4j+r][f]
+    const float *epi;        // [1+2R][3][16]           bias, bn scale, bn shift
+    const float *head;       // packed head parameters (offsets below)
+    int off_vk, off_v3, off_d1k, off_d1b, off_d2k, off_d2b, off_pk, off_p6, off_pdk, off_pdb;
+    uint64_t seed;
+    float alpha, eps;
+};
+
+template <class G, int PW_>
+struct NetGeom {
+    static constexpr int H = G::H, W = G::W, CIN = G::C, A = G::A;
+    static constexpr int PW = PW_;                     // positions per wave
+    static constexpr int HW = H * W;
+    static constexpr int SLOTS = (H + 2) * (W + 1) + 1; // pixel slots incl. zero halo
+    static constexpr int CP = (CIN + 3) / 4 * 4;       // input planes padded to a float4
+    static constexpr int NT = (PW * HW + 15) / 16;     // 16-pixel tiles per wave
+    static constexpr int STEPS0 = (9 * CIN + 3) / 4;   // MFMA k-steps of the first conv
+    static constexpr int ACT = PW * SLOTS * 16;        // floats per activation buffer
+    static constexpr int WAVE_FLOATS = 2 * ACT + PW * SLOTS * CP;
+    static constexpr int LDS_BYTES = 4 * WAVE_FLOATS * 4;
+    static_assert(LDS_BYTES <= 163840, "activations must fit the 160 KiB LDS");
+};
+
+template <class G, int PW>
+__global__ void __launch_bounds__(256, 1)
+k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *planes,
+              const uint32_t *game_id, const int32_t *serial, int noise, float *value_out, float *logits_out,
+              float *policy_out, int pstride) {
+    using NG = NetGeom<G, PW>;
+    constexpr int W = NG::W, CIN = NG::CIN, A = NG::A, HW = NG::HW, SLOTS = NG::SLOTS, CP = NG::CP,
+                  NT = NG::NT, STEPS0 = NG::STEPS0, ACT = NG::ACT;
+    __shared__ __attribute__((aligned(16))) float lds[4 * NG::WAVE_FLOATS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane >> 4, nn = lane & 15;
+    float *actA = lds + wave * NG::WAVE_FLOATS;
+    float *actB = actA + ACT;
+    float *inp = actB + ACT;
+    const int pos0 = (blockIdx.x * 4 + wave) * PW;
+    if (pos0 >= n) return; // whole wave idle (no block-level sync anywhere below)
+
+    // ---- zero this wave's LDS (halo pixels must read as 0 forever) --------------------------
+    {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 *p = (f32x4 *)actA;
+        for (int i = lane; i < NG::WAVE_FLOATS / 4; i += 64) p[i] = z;
+    }
+    // ---- input planes -> inp[pos][slot][CP] ---------------------------------------------------
+    for (int q = lane; q < PW * HW; q += 64) {
+        int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
+        int pos = pos0 + pp;
+        if (pos >= n) continue;
+        float *dst = inp + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * CP;
+        if (planes) {
+            const int8_t *src = planes + ((size_t)pos * HW + cell) * CIN;
+#pragma unroll
+            for (int c = 0; c < CIN; c++) dst[c] = (float)src[c];
+        } else {
+            int8_t v[3];
+            G::encode_cell(states[pos], y, x, v);
+            dst[0] = (float)v[0];
+            dst[1] = (float)v[1];
+            dst[2] = (float)v[2];
+        }
+    }
+    // ---- per-tile addressing: lane (j, nn) <-> pixel nn of the tile, channels 4j..4j+3 ---------
+    int aoff[NT];   // float offset of (pos, slot, channel 4j) inside an activation buffer
+    int ioff[NT];   // float offset of (pos, slot) inside inp
+    bool valid[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        int q = t * 16 + nn;
+        valid[t] = q < PW * HW;
+        int qq = valid[t] ? q : 0;
+        int pp = qq / HW, cell = qq % HW, y = cell / W, x = cell % W;
+        int slot = valid[t] ? (y + 1) * (W + 1) + (x + 1) : 0; // invalid lanes read the (zero) corner halo
+        aoff[t] = (pp * SLOTS + slot) * 16 + 4 * j;
+        ioff[t] = (pp * SLOTS + slot) * CP;
+    }
+    f32x4 acc[NT];
+    // ---- first conv: K = 9*CIN in natural (tap, c) order, 4 k per MFMA ---------------------------
+    {
+        const float *ep = nd.epi;
+        f32x4 bias = *(const f32x4 *)(ep + 4 * j), scale = *(const f32x4 *)(ep + 16 + 4 * j),
+              shift = *(const f32x4 *)(ep + 32 + 4 * j);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = bias;
+#pragma unroll
+        for (int s = 0; s < STEPS0; s++) {
+            int k = 4 * s + j;
+            int kk = k < 9 * CIN ? k : 9 * CIN - 1; // padded k: weight is 0, any readable address will do
+            int tap = kk / CIN, c = kk % CIN;
+            int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * CP + c;
+            float a = nd.w0[s * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                float b = inp[ioff[t] + toff];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; r++) y[r] = fmaxf(__builtin_fmaf(acc[t][r], scale[r], shift[r]), 0.f);
+            if (valid[t]) *(f32x4 *)(actA + aoff[t]) = y;
+        }
+    }
+    // ---- residual tower: 2R convs, K order (tap, r, j) with channel c = 4j + r ---------------------
+    const int L = 2 * nd.R;
+    for (int l = 0; l < L; l++) {
+        const float *in = (l & 1) ? actB : actA;
+        float *out = (l & 1) ? actA : actB;
+        const float *ep = nd.epi + (size_t)(1 + l) * 48;
+        f32x4 bias = *(const f32x4 *)(ep + 4 * j), scale = *(const f32x4 *)(ep + 16 + 4 * j),
+              shift = *(const f32x4 *)(ep + 32 + 4 * j);
+        f32x4 w[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) w[tap] = nd.wt[((size_t)l * 9 + tap) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = bias;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * 16;
+            f32x4 b[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) b[t] = *(const f32x4 *)(in + aoff[t] + toff);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][r], b[t][r], acc[t], 0, 0, 0);
+        }
+        const bool skip = (l & 1) != 0; // tf.add(batch_norm_2, block input) before the ReLU
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            f32x4 y;
+            f32x4 sk = {0.f, 0.f, 0.f, 0.f};
+            if (skip) sk = *(const f32x4 *)(out + aoff[t]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = __builtin_fmaf(acc[t][r], scale[r], shift[r]);
+                if (skip) v = v + sk[r];
+                y[r] = fmaxf(v, 0.f);
+            }
+            if (valid[t]) *(f32x4 *)(out + aoff[t]) = y;
+        }
+    }
+    // ---- heads (tower output is in actA; actB and inp are scratch now) --------------------------
+    const float *hp = nd.head;
+    float *rv = actB;               // [PW*HW] value-conv output
+    float *rp = actB + PW * HW;     // [PW*HW][2] policy-conv output
+    float *sd = rp + 2 * PW * HW;   // [PW][D]
+    float *lg = sd + PW * nd.D;     // [PW][A]
+    {
+        const float *vk = hp + nd.off_vk, *v3 = hp + nd.off_v3, *pk = hp + nd.off_pk, *p6 = hp + nd.off_p6;
+        for (int q = lane; q < PW * HW; q += 64) {
+            int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
+            const float *xp = actA + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * 16;
+            float av = v3[0], a0 = p6[0], a1 = p6[1];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++) {
+                f32x4 xv = *(const f32x4 *)(xp + 4 * c4);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int c = 4 * c4 + r;
+                    av = __builtin_fmaf(xv[r], vk[c], av);
+                    a0 = __builtin_fmaf(xv[r], pk[2 * c], a0);
+                    a1 = __builtin_fmaf(xv[r], pk[2 * c + 1], a1);
+                }
+            }
+            rv[q] = fmaxf(__builtin_fmaf(av, v3[1], v3[2]), 0.f);
+            rp[2 * q] = fmaxf(__builtin_fmaf(a0, p6[2], p6[4]), 0.f);
+            rp[2 * q + 1] = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
+        }
+    }
+    {
+        const int D = nd.D;
+        const float *d1k = hp + nd.off_d1k, *d1b = hp + nd.off_d1b;
+        for (int q = lane; q < PW * D; q += 64) { // dense_1 per pixel, then reduce_sum over H,W, ReLU
+            int pp = q / D, dd = q % D;
+            float s = 0.f, wk = d1k[dd], wb = d1b[dd];
+            for (int p = 0; p < HW; p++) s += __builtin_fmaf(rv[pp * HW + p], wk, wb);
+            sd[q] = fmaxf(s, 0.f);
+        }
+        const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
+        for (int q = lane; q < PW * A; q += 64) { // policy dense on the last axis, reduce_sum over H,W
+            int pp = q / A, a = q % A;
+            float s = 0.f, k0 = pdk[a], k1 = pdk[A + a], kb = pdb[a];
+            for (int p = 0; p < HW; p++)
+                s += __builtin_fmaf(rp[2 * (pp * HW + p) + 1], k1, __builtin_fmaf(rp[2 * (pp * HW + p)], k0, kb));
+            lg[q] = s;
+        }
+    }
+    if (lane < PW && pos0 + lane < n) { // one lane finishes each position (sequential, oracle order)
+        const int D = nd.D, pp = lane, pos = pos0 + lane;
+        const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
+        float e = d2b[0];
+        for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(sd[pp * D + dd], d2k[dd], e);
+        if (value_out) value_out[pos] = tanhf(e);
+        float m = -INFINITY;
+        for (int a = 0; a < A; a++) m = fmaxf(m, lg[pp * A + a]);
+        float pr[A];
+        float tot = 0.f;
+#pragma unroll
+        for (int a = 0; a < A; a++) {
+            float l = lg[pp * A + a];
+            if (logits_out) logits_out[(size_t)pos * A + a] = l;
+            pr[a] = expf(l - m);
+            tot += pr[a];
+        }
+#pragma unroll
+        for (int a = 0; a < A; a++) pr[a] = pr[a] / tot;
+        if (noise) { // policy = (1-eps)*softmax + eps*Beta(alpha,1-alpha); policy /= sum(policy)
+            float t2 = 0.f;
+            uint32_t gid = game_id ? game_id[pos] : 0u, ser = serial ? (uint32_t)serial[pos] : (uint32_t)pos;
+#pragma unroll
+            for (int a = 0; a < A; a++) {
+                pr[a] = (1.0f - nd.eps) * pr[a] + nd.eps * bb_beta_noise(nd.seed, gid, ser, (uint32_t)a, nd.alpha);
+                t2 += pr[a];
+            }
+#pragma unroll
+            for (int a = 0; a < A; a++) pr[a] = pr[a] / t2;
+        }
+        if (policy_out)
+#pragma unroll
+            for (int a = 0; a < A; a++) policy_out[(size_t)pos * pstride + a] = pr[a];
+    }
+}

@@ -1,0 +1,637 @@
+// tree.hip.h -- flat node-pool MCTS for dense-action games (Connect4, TicTacToe) on gfx950.
+//
+// One group of G::S lanes owns one game slot; lane i owns child slot i of the node row being
+// looked at (N/W/P/child live side by side in one node record, so a level costs one round trip).
+// Semantics follow the reference exactly (citations relative to /root/reference/src):
+//   select   MCTS._selectAction  MCTS.py:327-334  (float64 PUCT, first maximum wins)
+//            DynamicMCTS._findLeaf DynamicMCTS.py:14-34 / FixedMCTS._findLeaf FixedMCTS.py:21-34
+//   expand   MCTS.AddChildren MCTS.py:122-139 + Model.GetPriors Blackbird.py:372-389
+//   backup   MCTS._backProp MCTS.py:238-258 + Model.SampleValue Blackbird.py:350-370
+//   move     MCTS._selectAction(exploring=False) :335-338, _moveRoot :260-282,
+//            Blackbird.GenerateTrainingSamples Blackbird.py:238-268
+// Arithmetic types are the ones numpy>=2 gives the reference: float32 value/Value/WinRate,
+// float64 priors and PUCT.  (Rollout evaluator: Python floats -> float64 WinRate.)
+//
+// A node is created when a simulation first reaches it and is expanded in the same simulation
+// (the reference creates child Node objects eagerly in AddChildren but reads a child's priors
+// only once that child has children of its own, so this is observationally identical).
+#pragma once
+#include "games.hip.h"
+#include "rng.hip.h"
+
+#define NODE_EXPANDED 1
+#define NODE_TERMINAL 2
+#define CHILD_NONE (-1)
+#define CHILD_TERM_BIT 0x40000000
+
+template <class G>
+struct alignas(32) DenseNode {
+    typename G::State st; // 16 B
+    int32_t flags;
+    int32_t nlegal;
+    uint32_t legal_mask;
+    int32_t serial;
+    int32_t N[G::S];     // child.Plays
+    float W[G::S];       // child.Value
+    int32_t child[G::S]; // node index | CHILD_TERM_BIT, or CHILD_NONE
+    double P[G::S];      // Node.Priors
+};
+
+struct ExampleHdr { // 16 bytes, then packed state, then u32 visits[S]
+    uint32_t game_id;
+    uint16_t ply;
+    uint8_t player;
+    int8_t z;
+    uint32_t total;
+    uint32_t n_children;
+};
+
+struct TreeDev {
+    // configuration
+    int n_slots, node_cap, sims_per_move, max_plies, kind, max_depth, evaluator, priors_ones;
+    int salt_per_game, max_games;
+    double c_puct;
+    uint64_t seed, salt;
+    uint32_t first_game_id;
+    // per-slot tree state
+    int32_t *root, *root_N, *n_nodes, *ply, *sims_left, *pend_leaf, *pend_expand, *path_len;
+    int32_t *game_lid; // local game index played in this slot, -1 idle
+    int32_t *sim_serial;
+    float *root_W;
+    int8_t *root_pp; // Player of the root's parent state, 0 = root has no parent
+    uint32_t *path;  // [n_slots][MAXPATH]  node<<6 | player<<4 | action
+    // evaluator mailboxes
+    void *leaf_state;       // [n_slots] packed state of the pending leaf
+    uint32_t *leaf_game_id; // [n_slots]
+    int32_t *leaf_serial;   // [n_slots]
+    float *eval_value;      // [n_slots]
+    float *eval_policy;     // [n_slots][S]
+    uint64_t *ctr;          // [n_slots][8]: sims, sum_depth, nodes, terminal, games, plies, overflow, examples
+    void *nodes;            // [n_slots][node_cap]
+    // self-play
+    int n_games_target;
+    double temp;
+    uint8_t *examples; // [max_games][max_plies+1][example_bytes]
+    int32_t *game_hdr; // [max_games][4]: n_examples, winner, plies, done
+    int example_bytes;
+    // bb_sample_moves outputs (device staging)
+    int32_t *out_action, *out_root_plays, *out_child_plays;
+    float *out_root_winrate, *out_child_value;
+    const double *in_u; // optional uniforms
+};
+
+// ---- group (G::S lanes) collectives ---------------------------------------------------------
+template <int S>
+__device__ __forceinline__ int grp_sum_i(int v) {
+#pragma unroll
+    for (int o = S / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, S);
+    return v;
+}
+
+// numpy add.reduce over A float64 values held one per lane (A < 8: sequential; 8 <= A <= 128: 8 partials)
+template <int A, int S>
+__device__ __forceinline__ double grp_np_sum(double x) {
+    double a[A];
+#pragma unroll
+    for (int k = 0; k < A; k++) a[k] = __shfl(x, k, S);
+    if (A < 8) {
+        double res = 0.;
+#pragma unroll
+        for (int k = 0; k < A; k++) res += a[k];
+        return res;
+    } else {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        int i = 8;
+        for (; i < A - (A % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < A; i++) res += a[i];
+        return res;
+    }
+}
+
+// PUCT argmax over the group's lanes; u < 0 marks lanes that may not be chosen.
+template <int S>
+__device__ __forceinline__ int grp_argmax(double u, int idx) {
+#pragma unroll
+    for (int o = 1; o < S; o <<= 1) {
+        double ou = __shfl_xor(u, o, S);
+        int oi = __shfl_xor(idx, o, S);
+        if (ou > u || (ou == u && oi < idx)) {
+            u = ou;
+            idx = oi;
+        }
+    }
+    return idx;
+}
+
+template <class G>
+__device__ __forceinline__ double puct_score(const TreeDev &d, int Ni, float Wi, double Pi, int all, bool legal) {
+    double q;
+    if (Ni > 0) q = (d.evaluator == 2) ? (double)Wi / (double)Ni : (double)__fdiv_rn(Wi, (float)Ni);
+    else q = 0.0;
+    double sq = __dsqrt_rn(1.0 + (double)all);
+    double u = q + __ddiv_rn((d.c_puct * Pi) * sq, 1.0 + (double)Ni);
+    return legal ? u : -1.0;
+}
+
+// ---- phase A: apply the evaluator's answer for the pending leaf (expand + backup) -------------
+template <class G>
+__device__ void phase_apply(const TreeDev &d, int g, int lane) {
+    using Node = DenseNode<G>;
+    constexpr int S = G::S, A = G::A;
+    int leaf = d.pend_leaf[g];
+    if (leaf < 0) return;
+    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    Node *node = pool + leaf;
+    typename G::State st = node->st;
+    float v = d.eval_value[g];
+    if (d.pend_expand[g]) { // AddChildren with evaluator priors
+        uint32_t mask = G::legal_mask(st);
+        double x = 0.0;
+        if (lane < A) x = (double)d.eval_policy[(size_t)g * S + lane] * (double)((mask >> lane) & 1u);
+        double tot = grp_np_sum<A, S>(x);
+        node->N[lane] = 0;
+        node->W[lane] = 0.f;
+        node->child[lane] = CHILD_NONE;
+        node->P[lane] = (lane < A) ? __ddiv_rn(x, tot) : 0.0;
+        if (lane == 0) {
+            node->flags |= NODE_EXPANDED;
+            node->nlegal = __popc(mask);
+            node->legal_mask = mask;
+        }
+    }
+    int player = gs_player(st), prev = gs_prev(st);
+    float v01;
+    if (d.evaluator == 2) {
+        v01 = v; // rollout kernel already returns the value for `prev`
+    } else {
+        v01 = (v + 1.0f) * 0.5f; // Model.SampleValue: float32 arithmetic
+        if (player != prev) v01 = 1.0f - v01;
+    }
+    float vflip = 1.0f - v01;
+    int plen = d.path_len[g];
+    const uint32_t *path = d.path + (size_t)g * G::MAXPATH;
+    for (int k = lane; k < plen; k += S) { // _backProp: one (parent,action) edge per lane
+        uint32_t e = path[k];
+        int a = e & 15, pl = (e >> 4) & 3;
+        Node *pn = pool + (e >> 6);
+        pn->N[a] += 1;
+        pn->W[a] += (pl == prev) ? v01 : vflip;
+    }
+    if (lane == 0) {
+        d.root_N[g] += 1;
+        int pp = d.root_pp[g];
+        if (pp) d.root_W[g] += (pp == prev) ? v01 : vflip;
+        d.pend_leaf[g] = -1;
+    }
+}
+
+// allocate + initialise a child node (lane 0 writes).  nn = the slot's allocation cursor (register copy).
+// Returns the child word (index | TERM bit) or CHILD_NONE when the pool is exhausted.
+template <class G>
+__device__ __forceinline__ int create_child(const TreeDev &d, int g, DenseNode<G> *pool, DenseNode<G> *parent,
+                                            const typename G::State &pst, int a, int lane, int &nn,
+                                            typename G::State &st2, bool &terminal) {
+    int idx = nn;
+    st2 = pst;
+    G::apply(st2, a);
+    int w = G::winner(st2, a);
+    terminal = w >= 0;
+    if (idx >= d.node_cap) return CHILD_NONE;
+    int word = idx | (terminal ? CHILD_TERM_BIT : 0);
+    nn = idx + 1;
+    if (lane == 0) {
+        DenseNode<G> *c = pool + idx;
+        c->st = st2;
+        c->flags = terminal ? (NODE_TERMINAL | ((w + 1) << 8)) : 0;
+        c->nlegal = 0;
+        c->legal_mask = 0;
+        c->serial = idx;
+        parent->child[a] = word;
+        d.n_nodes[g] = idx + 1;
+        d.ctr[(size_t)g * 8 + 2] += 1;
+    }
+    return word;
+}
+
+// MCTS.GetPriors default: ones * LegalActions (MCTS.py:39,346-358).  Returns the legal mask.
+template <class G>
+__device__ __forceinline__ uint32_t expand_ones(DenseNode<G> *node, const typename G::State &st, int lane,
+                                                double &Pi) {
+    uint32_t mask = G::legal_mask(st);
+    Pi = (lane < G::A && ((mask >> lane) & 1u)) ? 1.0 : 0.0;
+    node->N[lane] = 0;
+    node->W[lane] = 0.f;
+    node->child[lane] = CHILD_NONE;
+    node->P[lane] = Pi;
+    if (lane == 0) {
+        node->flags |= NODE_EXPANDED;
+        node->nlegal = __popc(mask);
+        node->legal_mask = mask;
+    }
+    return mask;
+}
+
+// ---- phase B: one _findLeaf descent; leaves the leaf in the evaluator mailbox ------------------
+template <class G>
+__device__ void phase_select(const TreeDev &d, int g, int lane) {
+    using Node = DenseNode<G>;
+    constexpr int S = G::S, A = G::A;
+    if (d.game_lid[g] < 0 || d.sims_left[g] <= 0) return;
+    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    uint32_t *path = d.path + (size_t)g * G::MAXPATH;
+    int cur = d.root[g];
+    int nn = d.n_nodes[g];
+    int depth = 0, expand = 0, overflow = 0, term_leaf = 0;
+    const bool inline_expand = d.priors_ones != 0;
+    const bool fixed = d.kind == 1;
+    typename G::State st;
+    int flags = 0;
+    bool have = false; // st/flags of `cur` already in registers (node created this simulation)
+    for (int it = 0;; it++) {
+        Node *node = pool + cur;
+        if (!have) {
+            st = node->st;
+            flags = node->flags;
+        }
+        have = false;
+        if (fixed && it >= d.max_depth) break; // FixedMCTS: range(MaxDepth) exhausted
+        uint32_t mask;
+        int Ni, ci;
+        float Wi;
+        double Pi;
+        if (!(flags & NODE_EXPANDED)) {
+            if (flags & NODE_TERMINAL) { term_leaf = 1; break; } // Winner(lastAction) is not None
+            if (!inline_expand) { expand = 1; break; }            // AddChildren once the evaluator has answered
+            mask = expand_ones<G>(node, st, lane, Pi);
+            if (!fixed) break; // DynamicMCTS: AddChildren(node); break
+            Ni = 0;
+            Wi = 0.f;
+            ci = CHILD_NONE;
+        } else {
+            mask = node->legal_mask;
+            Ni = node->N[lane];
+            Wi = node->W[lane];
+            Pi = node->P[lane];
+            ci = node->child[lane];
+        }
+        if (mask == 0) break; // np.sum(LegalActions) == 0
+        int all = grp_sum_i<S>(lane < A ? Ni : 0);
+        double u = puct_score<G>(d, Ni, Wi, Pi, all, lane < A && ((mask >> lane) & 1u));
+        int a = grp_argmax<S>(u, lane);
+        int child = __shfl(ci, a, S);
+        if (depth >= G::MAXPATH) { overflow = 1; break; }
+        if (child == CHILD_NONE) {
+            typename G::State st2;
+            bool terminal;
+            child = create_child<G>(d, g, pool, node, st, a, lane, nn, st2, terminal);
+            if (child == CHILD_NONE) { overflow = 1; break; }
+            if (lane == 0) path[depth] = ((uint32_t)cur << 6) | ((uint32_t)gs_player(st) << 4) | (uint32_t)a;
+            st = st2;
+            flags = terminal ? NODE_TERMINAL : 0;
+            have = true;
+        } else {
+            if (lane == 0) path[depth] = ((uint32_t)cur << 6) | ((uint32_t)gs_player(st) << 4) | (uint32_t)a;
+        }
+        depth++;
+        cur = child & ~CHILD_TERM_BIT;
+    }
+    if (lane == 0) {
+        ((typename G::State *)d.leaf_state)[g] = st;
+        d.leaf_game_id[g] = d.first_game_id + (uint32_t)d.game_lid[g];
+        d.leaf_serial[g] = cur;
+        d.pend_leaf[g] = cur;
+        d.pend_expand[g] = expand;
+        d.path_len[g] = depth;
+        d.sims_left[g] -= 1;
+        d.sim_serial[g] += 1;
+        uint64_t *c = d.ctr + (size_t)g * 8;
+        c[0] += 1;
+        c[1] += (uint64_t)depth;
+        c[3] += (uint64_t)term_leaf;
+        c[6] += (uint64_t)overflow;
+    }
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_tree_step(TreeDev d) {
+    constexpr int S = G::S;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int g = t / S, lane = t % S;
+    if (g >= d.n_slots) return;
+    phase_apply<G>(d, g, lane);
+    __threadfence_block();
+    phase_select<G>(d, g, lane);
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_tree_apply(TreeDev d) {
+    constexpr int S = G::S;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int g = t / S, lane = t % S;
+    if (g >= d.n_slots) return;
+    phase_apply<G>(d, g, lane);
+}
+
+// ---- root statistics + move choice -------------------------------------------------------------
+// returns the chosen action (same on every lane) or -4 (NaN probabilities) / -3 (no tree)
+template <class G>
+__device__ int choose_move(const TreeDev &d, int g, int lane, double temp, double u, int &total, int &Ni_out,
+                           float &Wi_out) {
+    using Node = DenseNode<G>;
+    constexpr int S = G::S, A = G::A;
+    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    Node *node = pool + d.root[g];
+    if (!(node->flags & NODE_EXPANDED)) {
+        total = 0;
+        Ni_out = 0;
+        Wi_out = 0.f;
+        return -3;
+    }
+    uint32_t mask = node->legal_mask;
+    bool legal = lane < A && ((mask >> lane) & 1u);
+    int Ni = legal ? node->N[lane] : 0;
+    float Wi = legal ? node->W[lane] : 0.f;
+    Ni_out = Ni;
+    Wi_out = Wi;
+    int all = grp_sum_i<S>(Ni);
+    total = all;
+    if (temp == 0.0) { // `exploring or temp == 0` -> PUCT argmax (MCTS.py:327-334)
+        double uu = puct_score<G>(d, Ni, Wi, node->P[lane], all, legal);
+        return grp_argmax<S>(uu, lane);
+    }
+    // p_i = N_i^(1/temp) / sum; np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, 'right')
+    double it = 1.0 / temp;
+    double w = (it == 1.0) ? (double)Ni : pow((double)Ni, it);
+    double ws[A];
+#pragma unroll
+    for (int k = 0; k < A; k++) ws[k] = __shfl(w, k, S);
+    double allp = 0.0;
+#pragma unroll
+    for (int k = 0; k < A; k++) allp += ws[k];
+    if (!(allp > 0.0)) return -4;
+    double last = 0.0;
+#pragma unroll
+    for (int k = 0; k < A; k++) last += __ddiv_rn(ws[k], allp);
+    double run = 0.0;
+    int act = A - 1;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < A; k++) {
+        run += __ddiv_rn(ws[k], allp);
+        if (!found && __ddiv_rn(run, last) > u) {
+            act = k;
+            found = true;
+        }
+    }
+    return act;
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_sample(TreeDev d, double temp) {
+    constexpr int S = G::S;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int g = t / S, lane = t % S;
+    if (g >= d.n_slots) return;
+    if (d.game_lid[g] < 0) {
+        if (lane == 0 && d.out_action) d.out_action[g] = -3;
+        return;
+    }
+    double u = d.in_u ? d.in_u[g] : bb_u53(d.seed, d.first_game_id + (uint32_t)d.game_lid[g], (uint32_t)d.ply[g]);
+    int total, Ni;
+    float Wi;
+    int act = choose_move<G>(d, g, lane, temp, u, total, Ni, Wi);
+    if (d.out_child_plays) d.out_child_plays[(size_t)g * S + lane] = Ni;
+    if (d.out_child_value) d.out_child_value[(size_t)g * S + lane] = Wi;
+    if (lane == 0) {
+        if (d.out_action) d.out_action[g] = act;
+        if (d.out_root_plays) d.out_root_plays[g] = d.root_N[g];
+        if (d.out_root_winrate) {
+            int n = d.root_N[g];
+            float w = d.root_W[g];
+            d.out_root_winrate[g] = n > 0 ? ((d.evaluator == 2) ? (float)((double)w / (double)n) : __fdiv_rn(w, (float)n)) : 0.f;
+        }
+    }
+}
+
+// _moveRoot by action.  Lane-0 state updates; all lanes of the group call it.
+template <class G>
+__device__ void advance_root(const TreeDev &d, int g, int lane, int a, typename G::State &new_st) {
+    using Node = DenseNode<G>;
+    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    Node *node = pool + d.root[g];
+    typename G::State st = node->st;
+    if (!(node->flags & NODE_EXPANDED)) { // `Root.Children is None` -> Root = None; re-prime with the new state
+        new_st = st;
+        G::apply(new_st, a);
+        if (lane == 0) {
+            Node *r = pool;
+            r->st = new_st;
+            r->flags = 0;
+            r->serial = 0;
+            d.n_nodes[g] = 1;
+            d.root[g] = 0;
+            d.root_N[g] = 0;
+            d.root_W[g] = 0.f;
+            d.root_pp[g] = 0;
+        }
+        return;
+    }
+    int child = node->child[a];
+    int cn = node->N[a];
+    float cw = node->W[a];
+    if (child == CHILD_NONE) {
+        bool terminal;
+        int nn = d.n_nodes[g];
+        child = create_child<G>(d, g, pool, node, st, a, lane, nn, new_st, terminal);
+        if (child == CHILD_NONE) { // pool exhausted: restart the tree at the new state
+            child = 0;
+            cn = 0;
+            cw = 0.f;
+            if (lane == 0) {
+                pool->st = new_st;
+                pool->flags = 0;
+                d.n_nodes[g] = 1;
+                d.ctr[(size_t)g * 8 + 6] += 1;
+            }
+        }
+    } else {
+        new_st = pool[child & ~CHILD_TERM_BIT].st;
+    }
+    if (lane == 0) {
+        d.root[g] = child & ~CHILD_TERM_BIT;
+        d.root_N[g] = cn;
+        d.root_W[g] = cw;
+        d.root_pp[g] = (int8_t)gs_player(st);
+    }
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_move_roots(TreeDev d, const int32_t *actions) {
+    constexpr int S = G::S;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int g = t / S, lane = t % S;
+    if (g >= d.n_slots) return;
+    int a = actions[g];
+    if (a < 0 || a >= G::A || d.game_lid[g] < 0) return;
+    typename G::State ns;
+    advance_root<G>(d, g, lane, a, ns);
+    if (lane == 0) d.ply[g] += 1;
+}
+
+template <class G>
+__device__ __forceinline__ void reset_slot(const TreeDev &d, int g, int lid, const typename G::State &st) {
+    using Node = DenseNode<G>;
+    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    pool->st = st;
+    pool->flags = 0;
+    pool->nlegal = 0;
+    pool->legal_mask = 0;
+    pool->serial = 0;
+    d.n_nodes[g] = 1;
+    d.root[g] = 0;
+    d.root_N[g] = 0;
+    d.root_W[g] = 0.f;
+    d.root_pp[g] = 0;
+    d.ply[g] = 0;
+    d.pend_leaf[g] = -1;
+    d.pend_expand[g] = 0;
+    d.path_len[g] = 0;
+    d.sim_serial[g] = 0;
+    d.game_lid[g] = lid;
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_set_roots(TreeDev d, int n, const int32_t *slots,
+                                                   const typename G::State *states, const uint32_t *game_ids) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int g = slots ? slots[i] : i;
+    if (g < 0 || g >= d.n_slots) return;
+    reset_slot<G>(d, g, game_ids ? (int)game_ids[i] : g, states[i]);
+    d.sims_left[g] = 0;
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_add_sims(TreeDev d, int sims) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.n_slots) return;
+    if (d.game_lid[g] >= 0) d.sims_left[g] = sims;
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_get_roots(TreeDev d, typename G::State *out) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.n_slots) return;
+    out[g] = ((DenseNode<G> *)d.nodes + (size_t)g * d.node_cap + d.root[g])->st;
+}
+
+// ---- self-play: begin / one move for every slot --------------------------------------------------
+template <class G>
+__global__ void __launch_bounds__(256) k_selfplay_begin(TreeDev d) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.n_slots) return;
+    if (g < d.n_games_target) {
+        reset_slot<G>(d, g, g, G::initial());
+        d.sims_left[g] = d.sims_per_move;
+    } else {
+        reset_slot<G>(d, g, -1, G::initial());
+        d.sims_left[g] = 0;
+    }
+}
+
+template <class G>
+__device__ __forceinline__ uint8_t *example_ptr(const TreeDev &d, int lid, int ply) {
+    return d.examples + ((size_t)lid * (d.max_plies + 1) + ply) * d.example_bytes;
+}
+
+template <class G>
+__device__ void write_example(const TreeDev &d, int lid, int ply, const typename G::State &st, int lane, int Ni,
+                              int total, uint32_t gid) {
+    uint8_t *p = example_ptr<G>(d, lid, ply);
+    if (lane == 0) {
+        ExampleHdr h;
+        h.game_id = gid;
+        h.ply = (uint16_t)ply;
+        h.player = (uint8_t)gs_player(st);
+        h.z = 0;
+        h.total = (uint32_t)total;
+        h.n_children = G::A;
+        *(ExampleHdr *)p = h;
+        *(typename G::State *)(p + sizeof(ExampleHdr)) = st;
+    }
+    ((uint32_t *)(p + sizeof(ExampleHdr) + sizeof(typename G::State)))[lane] = (uint32_t)Ni;
+}
+
+// apply the last pending leaf, then FindMove's tail + the body of GenerateTrainingSamples' while loop
+template <class G>
+__global__ void __launch_bounds__(256) k_selfplay_move(TreeDev d) {
+    using Node = DenseNode<G>;
+    constexpr int S = G::S;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int g = t / S, lane = t % S;
+    if (g >= d.n_slots) return;
+    phase_apply<G>(d, g, lane);
+    __threadfence_block();
+    int lid = d.game_lid[g];
+    if (lid < 0) return;
+    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    typename G::State st = pool[d.root[g]].st;
+    uint32_t gid = d.first_game_id + (uint32_t)lid;
+    int ply = d.ply[g];
+    double u = bb_u53(d.seed, gid, (uint32_t)ply);
+    int total, Ni;
+    float Wi;
+    int act = choose_move<G>(d, g, lane, d.temp, u, total, Ni, Wi);
+    if (act < 0) { // cannot happen with sims_per_move >= 2; park the slot
+        if (lane == 0) {
+            d.game_lid[g] = -1;
+            d.ctr[(size_t)g * 8 + 6] += 1;
+        }
+        return;
+    }
+    write_example<G>(d, lid, ply, st, lane, Ni, total, gid); // (s, pi, player) of the state before the move
+    typename G::State ns;
+    advance_root<G>(d, g, lane, act, ns);
+    __threadfence_block();
+    ply += 1;
+    int w = G::winner(ns, -1); // state.Winner(lastAction=None): full scan (Blackbird.py:253)
+    bool over = w >= 0 || ply >= d.max_plies;
+    if (!over) {
+        if (lane == 0) {
+            d.ply[g] = ply;
+            d.sims_left[g] = d.sims_per_move;
+            d.ctr[(size_t)g * 8 + 5] += 1;
+        }
+        return;
+    }
+    // terminal example with pi = zeros (Blackbird.py:256-258), then z for every example (:260-264)
+    write_example<G>(d, lid, ply, ns, lane, 0, 0, gid);
+    __threadfence_block();
+    for (int k = lane; k <= ply; k += S) {
+        ExampleHdr *h = (ExampleHdr *)example_ptr<G>(d, lid, k);
+        h->z = (w <= 0) ? 0 : (h->player == w ? 1 : -1);
+    }
+    if (lane == 0) {
+        int32_t *gh = d.game_hdr + (size_t)lid * 4;
+        gh[0] = ply + 1;
+        gh[1] = w;
+        gh[2] = ply;
+        gh[3] = 1;
+        uint64_t *c = d.ctr + (size_t)g * 8;
+        c[4] += 1;
+        c[5] += 1;
+        c[7] += (uint64_t)(ply + 1);
+        int next = lid + d.n_slots; // this slot's next game id
+        if (next < d.n_games_target) {
+            reset_slot<G>(d, g, next, G::initial());
+            d.sims_left[g] = d.sims_per_move;
+        } else {
+            d.game_lid[g] = -1;
+            d.sims_left[g] = 0;
+        }
+    }
+}

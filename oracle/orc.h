@@ -92,6 +92,7 @@ typedef struct {
     float alpha, eps;
     orc_eval_cb cb;
     void *cb_ctx;
+    int priors_ones; /* MCTS.GetPriors default (MCTS.py:346-358): ones -> Priors = legal mask */
 } orc_cfg;
 
 typedef struct {

@@ -49,7 +49,7 @@ class Cfg(C.Structure):
     _fields_ = [("game", C.c_int), ("kind", C.c_int), ("max_depth", C.c_int), ("evaluator", C.c_int),
                 ("c_puct", C.c_double), ("salt", C.c_uint64), ("seed", C.c_uint64),
                 ("net", C.POINTER(Net)), ("noise_on", C.c_int), ("alpha", C.c_float), ("eps", C.c_float),
-                ("cb", EVAL_CB), ("cb_ctx", C.c_void_p)]
+                ("cb", EVAL_CB), ("cb_ctx", C.c_void_p), ("priors_ones", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -209,11 +209,12 @@ def net_forward(w, boards):
 
 # ---- search -----------------------------------------------------------------------------
 def make_cfg(game, kind=DYNAMIC, evaluator=EVAL_HASH, c_puct=0.85, max_depth=10, salt=0, seed=1234,
-             net=None, noise_on=False, alpha=0.2, eps=0.3, cb=None):
+             net=None, noise_on=False, alpha=0.2, eps=0.3, cb=None, priors_ones=False):
     c = Cfg()
     c.game, c.kind, c.max_depth, c.evaluator = game, kind, max_depth, evaluator
     c.c_puct, c.salt, c.seed = c_puct, salt, seed
     c.noise_on, c.alpha, c.eps = int(noise_on), alpha, eps
+    c.priors_ones = int(priors_ones)
     if net is not None:
         c.net = C.pointer(net.c)
         c._net_keep = net

@@ -252,7 +252,7 @@ static void node_prepare(orc_search *s, orc_node *n, const float *policy) {
     int k = 0;
     for (int a = 0; a < A; a++)
         if (legal[a] == 1.0) n->act[k++] = a;
-    if (s->cfg.evaluator == ORC_EVAL_ROLLOUT) {
+    if (s->cfg.evaluator == ORC_EVAL_ROLLOUT || s->cfg.priors_ones) {
         for (k = 0; k < nl; k++) n->prior[k] = 1.0;
     } else {
         float v;
@@ -364,7 +364,7 @@ static double sample_value(orc_search *s, orc_node *leaf, const float *net_value
 
 /* MCTS._backProp, MCTS.py:238-258 (recursion written as a loop; walks past the current root
  * through stale ancestors exactly like the reference, whose _moveRoot never clears Parent) */
-static void back_prop(orc_search *s, orc_node *leaf, double v, int player_for_value) {
+static void back_prop(orc_node *leaf, double v, int player_for_value) {
     float vf = (float)v;
     for (orc_node *n = leaf; n; n = n->parent) {
         n->N += 1;
@@ -423,7 +423,7 @@ static void run_sim(orc_search *s) {
         }
     }
     double v = sample_value(s, node, have_value ? &net_value : NULL);
-    back_prop(s, node, v, node->st.prev);
+    back_prop(node, v, node->st.prev);
     s->stats.sims++;
     s->sim_serial++;
     s->stats.sum_depth += (uint64_t)depth;

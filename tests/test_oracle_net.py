@@ -1,0 +1,92 @@
+"""Oracle network forward (oracle/orc_net.c) vs an independent PyTorch-CPU statement of the graph
+NetworkFactory.__call__ builds (NetworkFactory.py:22-183).  The reference's own network cannot
+run here (TensorFlow absent) -> this is the "parity unpinned" cross-check, tolerance 1e-5."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+from blackbird_amd import weights as W
+
+
+def torch_forward(w, boards):
+    """float32, NHWC semantics of TF reproduced with NCHW torch ops."""
+    C, F, R, D, A = W.infer_shape(w)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))  # noqa: E731
+
+    def conv(x, name):
+        k = t(w[f"{name}/kernel"]).permute(3, 2, 0, 1).contiguous()  # HWIO -> OIHW
+        pad = k.shape[-1] // 2
+        return Fn.conv2d(x, k, t(w[f"{name}/bias"]), padding=pad)
+
+    def bn(x, name):
+        g, b, m, v = (t(w[f"{name}/{f}"]).view(1, -1, 1, 1) for f in W.BN_FIELDS)
+        return g * (x - m) / torch.sqrt(v + 1e-3) + b
+
+    x = torch.from_numpy(boards.astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+    x = torch.relu(bn(conv(x, "resTower/conv_block/conv"), "resTower/conv_block/batch_norm"))
+    for i in range(R):
+        h = torch.relu(bn(conv(x, f"resTower/block_{i}/conv_1"), f"resTower/block_{i}/batch_norm_1"))
+        h = bn(conv(h, f"resTower/block_{i}/conv_2"), f"resTower/block_{i}/batch_norm_2")
+        x = torch.relu(h + x)
+    # value head: 1x1 conv -> BN -> relu -> dense(1->D) on last axis -> sum over H,W -> relu -> dense(D->1) -> tanh
+    v = torch.relu(bn(conv(x, "value/convolution"), "value/batch_norm")).permute(0, 2, 3, 1)  # NHWC, C=1
+    v = v @ t(w["value/dense_1/kernel"]) + t(w["value/dense_1/bias"])  # [B,H,W,D]
+    v = torch.relu(v.sum(dim=(1, 2)))
+    v = (v @ t(w["value/dense_2/kernel"]) + t(w["value/dense_2/bias"])).sum(dim=1)
+    value = torch.tanh(v)
+    p = torch.relu(bn(conv(x, "policy/convolution"), "policy/batch_norm")).permute(0, 2, 3, 1)  # [B,H,W,2]
+    p = p @ t(w["policy/policy/kernel"]) + t(w["policy/policy/bias"])  # [B,H,W,A]
+    logits = p.sum(dim=(1, 2))
+    return value.numpy(), logits.numpy(), torch.softmax(logits, dim=1).numpy()
+
+
+CASES = [  # (game, H, W, C, F, R, D, A)
+    ("c4", 6, 7, 3, 16, 4, 16, 7),
+    ("ttt", 3, 3, 3, 16, 4, 16, 9),
+    ("dc", 8, 8, 17, 16, 2, 16, 4032),
+    ("c4wide", 6, 7, 3, 64, 2, 16, 7),
+]
+
+
+def random_boards(rng, n, H, Wd, C):
+    b = np.zeros((n, H, Wd, C), dtype=np.int8)
+    if C == 3:
+        cells = rng.randint(0, 3, size=(n, H, Wd))
+        b[..., 0] = cells == 1
+        b[..., 1] = cells == 2
+        b[..., 2] = rng.choice([-1, 1], size=(n, 1, 1))
+    else:
+        b[...] = rng.rand(n, H, Wd, C) < 0.15
+    return b
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_oracle_net_vs_torch(orc, case, perturb):
+    _, H, Wd, C, F, R, D, A = case
+    w = W.init_weights(C, F, R, D, A, seed=3, perturb=perturb)
+    ow = orc.NetWeights(H, Wd, C, F, R, D, A, W.flatten(w))
+    rng = np.random.RandomState(1)
+    boards = random_boards(rng, 6, H, Wd, C)
+    v, lg, pol = orc.net_forward(ow, boards)
+    tv, tl, tp = torch_forward(w, boards)
+    # tolerance 1e-5 (north star), relative to max(1,|x|) for logits
+    assert np.max(np.abs(v - tv)) <= 1e-5
+    assert np.max(np.abs(lg - tl) / np.maximum(1.0, np.abs(tl))) <= 1e-5
+    assert np.max(np.abs(pol - tp)) <= 1e-5
+    assert np.allclose(pol.sum(1), 1.0, atol=1e-5)
+
+
+def test_pool_then_dense_identity(orc):
+    # algebraic identity of the heads: sum_p (r_p W + b) == (sum_p r_p) W + HW*b  (SURVEY 2.3 rows 7,10)
+    H, Wd, C, F, R, D, A = 6, 7, 3, 16, 1, 16, 7
+    w = W.init_weights(C, F, R, D, A, seed=5, perturb=True)
+    ow = orc.NetWeights(H, Wd, C, F, R, D, A, W.flatten(w))
+    boards = random_boards(np.random.RandomState(2), 4, H, Wd, C)
+    _, lg, _ = orc.net_forward(ow, boards)
+    w2 = dict(w)
+    w2["policy/policy/bias"] = np.zeros(A, np.float32)
+    ow2 = orc.NetWeights(H, Wd, C, F, R, D, A, W.flatten(w2))
+    _, lg0, _ = orc.net_forward(ow2, boards)
+    assert np.allclose(lg - lg0, H * Wd * w["policy/policy/bias"][None, :], atol=1e-4)
