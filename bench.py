@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play throughput of the MI355X engine on BASELINE.json's headline configuration.
+
+Workload (configs[1], "C2"): Connect4 7x6, 800 simulations/move, 4096 concurrent self-play games
+per GPU, network R4/F16/D16 random-init (weight seed 0), c_puct 0.85, temp 1, Beta prior noise
+alpha 0.2 / eps 0.3 (always on in the reference, NetworkFactory.py:176-180), float32.
+
+A "step" is one ply of every concurrent game: 800 x (tree kernel + network kernel) + one move
+kernel.  Finished games hand their slot to a fresh game, so the batch stays full; `value` is
+games completed inside the timed region / wall time (whole job, all ranks).  Before warm-up the
+games are de-synchronised by an untimed prefill at 32 simulations/move (otherwise all 4096 games
+would start and finish in lock-step and a short timed window would see no completions).
+
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL), disjoint game-id/RNG
+streams per rank, no collective in the data path; the (s, pi, z) examples of the timed region are
+all-gathered once after timing (the epoch-end exchange of SURVEY.md 8e).
+
+usage: python bench.py [--gpus N] [--steps K] [--warmup W]
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from blackbird_amd import _lib, weights as W  # noqa: E402
+
+FLOPS_PER_EVAL = 1_588_700  # SURVEY.md 8d / BASELINE.md: C2 network, conv + heads
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def cpu_baseline(flat, seconds_budget=20.0, sims=800):
+    """Oracle ("port" of the reference's serial algorithm) on the host cores: one independent
+    game per thread, same network/seed/noise as the GPU run.  Bounded: one game per thread."""
+    from oracle import orc
+    ow = orc.NetWeights(6, 7, 3, 16, 4, 16, 7, flat)
+    cfg = orc.make_cfg(orc.C4, evaluator=orc.EVAL_NET, net=ow, noise_on=True, alpha=0.2, eps=0.3, seed=1234)
+    cores = min(os.cpu_count() or 1, 16)
+    res = [None] * cores
+
+    def work(i):
+        res[i] = orc.selfplay_game(cfg, 10_000_000 + i, 1.0, sims, 42)
+
+    t0 = time.time()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.time() - t0
+    tot_sims = sum(r["stats"].sims for r in res)
+    return {"value": cores / dt, "unit": "games/s", "cores": cores, "kind": "port",
+            "sims_per_s": tot_sims / dt,
+            "sample": f"{cores} full Connect4 games at {sims} sims/move, one per host thread, "
+                      f"{sum(r['n'] - 1 for r in res)} plies, {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--slots", type=int, default=4096)
+    ap.add_argument("--sims", type=int, default=800)
+    ap.add_argument("--prefill", type=int, default=64, help="untimed de-synchronisation plies at 32 sims/move")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    game = _lib.GAME_CONNECT4
+    K, Wm = args.steps, args.warmup
+    flat = W.flatten(W.init_weights(3, 16, 4, 16, 7, seed=0))
+    total_plies = args.prefill + Wm + K + 2
+    # every slot finishes at most one game per 7 plies (shortest Connect4 game)
+    max_games = args.slots * (total_plies // 7 + 2)
+    eng = _lib.Engine(game, n_slots=args.slots, sims_per_move=args.sims, evaluator=_lib.EVAL_NET, c_puct=0.85,
+                      seed=1234 + rank, first_game_id=rank * 50_000_000, noise_on=True, alpha=0.2, epsilon=0.3,
+                      device=local, max_games=max_games)
+    eng.load_weights(flat)
+    eng.selfplay_begin(max_games, 1.0)
+    if args.prefill > 0:
+        eng.set_sims_per_move(32)
+        eng.selfplay_step(args.prefill)
+        eng.set_sims_per_move(args.sims)
+    if Wm > 0:
+        eng.selfplay_step(Wm)
+    eng.synchronize()
+    eng.reset_counters()
+    eng.timing_enable(97)  # HIP events around every 97th network launch of the timed region
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    barrier()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    eng.selfplay_step(K)
+    eng.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    cnt = eng.counters()
+    net_ms, net_min_ms, net_n = eng.timing_read()
+    games, sims, plies = cnt["games_finished"], cnt["sims"], cnt["plies"]
+    tot = np.array([games, sims, plies, dt], dtype=np.float64)
+    if dist is not None:
+        import torch
+        t = torch.tensor(tot, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        games, sims, plies = [float(x) for x in t[:3].tolist()]
+        dt = float(tmax[3])
+        # epoch-end exchange: all-gather the examples generated in the timed region
+        done_flags = np.zeros(1)
+        rec, offs, win = eng.fetch_examples(0, max_games)
+        payload = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
+        n_local = torch.tensor([payload.numel()], device="cuda", dtype=torch.int64)
+        sizes = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(sizes, n_local)
+        mx = int(max(int(s) for s in sizes))
+        pad = torch.zeros(mx, dtype=torch.uint8, device="cuda")
+        pad[:payload.numel()] = payload
+        gathered = [torch.empty_like(pad) for _ in range(world)]
+        tg = time.perf_counter()
+        dist.all_gather(gathered, pad)
+        torch.cuda.synchronize()
+        allgather_s = time.perf_counter() - tg
+        del done_flags
+    else:
+        allgather_s = None
+
+    if rank == 0:
+        evals_per_launch = args.slots
+        achieved = FLOPS_PER_EVAL * evals_per_launch / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
+        out = {
+            "metric": "selfplay_games_per_sec", "value": games / dt, "unit": "games/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (self-play from the initial position, random-init weights seed 0)",
+            "config": {"workload": "Connect4 7x6, DynamicMCTS 800 sims/move, %d concurrent games per GPU, "
+                                   "net R4/F16/D16 fp32, noise alpha 0.2 eps 0.3 (BASELINE configs[1])" % args.slots,
+                       "game": "Connect4", "sims_per_move": args.sims, "concurrent_games_per_gpu": args.slots,
+                       "blocks": 4, "filters": 16, "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
+            "node_evals_per_sec": sims / dt, "plies_per_sec": plies / dt, "games_finished": games,
+            "mean_leaf_depth": cnt["sum_depth"] / max(cnt["sims"], 1), "overflow": cnt["overflow"],
+            "roofline": {"bound": "mfma", "kernel": "k_net_fused16<Connect4,4>", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "launch_ms_mean": net_ms, "launch_ms_min": net_min_ms,
+                         "launches_timed": net_n, "flops_per_launch": FLOPS_PER_EVAL * evals_per_launch},
+        }
+        if allgather_s is not None:
+            out["examples_allgather_s"] = allgather_s
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(flat)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -166,9 +166,15 @@ struct bb_engine {
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
     int n_games_target = 0;
+    int sims_now = 0;
     size_t node_bytes = 0;
     double *d_u = nullptr;
     int32_t *d_actions = nullptr;
+    // optional HIP-event timing of the evaluator launches
+    int time_every = 0;
+    uint64_t eval_launches = 0;
+    std::vector<hipEvent_t> ev_pool; // pairs (start, stop)
+    size_t ev_used = 0;
 };
 
 template <class T>
@@ -230,6 +236,7 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     if (cfg->device < 0 || cfg->device >= ndev) return fail(BB_ERR_ARG, "device %d out of range", cfg->device);
     bb_engine *e = new bb_engine();
     e->cfg = *cfg;
+    e->sims_now = cfg->sims_per_move;
     int rc = bb_game_info_get(cfg->game, &e->info);
     if (rc) {
         delete e;
@@ -273,8 +280,44 @@ extern "C" int bb_destroy(bb_engine *e) {
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (void *p : e->allocs) (void)hipFree(p);
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
+    return BB_OK;
+}
+
+extern "C" int bb_timing_enable(bb_engine *e, int every_n) {
+    if (!e || every_n < 0) return fail(BB_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (every_n > 0 && e->ev_pool.empty()) {
+        e->ev_pool.resize(2 * 512);
+        for (auto &ev : e->ev_pool) HIPCHK(hipEventCreate(&ev));
+    }
+    e->time_every = every_n;
+    e->eval_launches = 0;
+    e->ev_used = 0;
+    return BB_OK;
+}
+
+extern "C" int bb_timing_read(bb_engine *e, double *mean_ms_out, double *min_ms_out, int *count_out) {
+    if (!e) return fail(BB_ERR_ARG, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    double sum = 0.0, mn = 1e30;
+    int cnt = 0;
+    for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]));
+        sum += ms;
+        if (ms < mn) mn = ms;
+        cnt++;
+    }
+    if (mean_ms_out) *mean_ms_out = cnt ? sum / cnt : 0.0;
+    if (min_ms_out) *min_ms_out = cnt ? mn : 0.0;
+    if (count_out) *count_out = cnt;
+    e->ev_used = 0;
+    e->eval_launches = 0;
     return BB_OK;
 }
 
@@ -442,7 +485,24 @@ extern "C" int bb_hash_eval(bb_engine *e, int n, const void *states, float *valu
 
 // ---- simulation loop ---------------------------------------------------------------------------------
 template <class G>
+static int launch_eval_inner(bb_engine *e);
+
+template <class G>
 static int launch_eval(bb_engine *e) {
+    bool timed = e->time_every > 0 && (e->eval_launches++ % (uint64_t)e->time_every) == 0 &&
+                 e->ev_used + 2 <= e->ev_pool.size();
+    if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
+    int rc = launch_eval_inner<G>(e);
+    if (rc) return rc;
+    if (timed) {
+        HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
+        e->ev_used += 2;
+    }
+    return BB_OK;
+}
+
+template <class G>
+static int launch_eval_inner(bb_engine *e) {
     TreeDev &d = e->dev;
     int n = d.n_slots;
     const typename G::State *ls = (const typename G::State *)d.leaf_state;
@@ -583,13 +643,28 @@ extern "C" int bb_get_root_states(bb_engine *e, void *states_out) {
     });
 }
 
+extern "C" int bb_set_sims_per_move(bb_engine *e, int sims) {
+    if (!e || sims <= 0) return fail(BB_ERR_ARG, "bad arguments");
+    long need = (long)sims * e->cfg.max_plies + 2;
+    if (e->cfg.node_capacity <= 0 && sims > e->cfg.sims_per_move && need > e->dev.node_cap)
+        return fail(BB_ERR_CAPACITY, "node pool was sized for %d simulations per move", e->cfg.sims_per_move);
+    HIPCHK(hipSetDevice(e->cfg.device));
+    e->sims_now = sims;
+    e->dev.sims_per_move = sims;
+    GAME_SWITCH(e->cfg.game, {
+        k_add_sims<G><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, sims); // slots waiting for their next move
+        HIPCHK(hipGetLastError());
+        return BB_OK;
+    });
+}
+
 // ---- self-play ----------------------------------------------------------------------------------------
 extern "C" int bb_selfplay_begin(bb_engine *e, int n_games, double temp) {
     if (!e) return fail(BB_ERR_ARG, "null engine");
     if (n_games <= 0) return fail(BB_ERR_ARG, "Use a positive integer for number of games."); // Blackbird.py:235-236
     if (n_games > e->cfg.max_games)
         return fail(BB_ERR_CAPACITY, "n_games %d exceeds the engine's max_games %d", n_games, e->cfg.max_games);
-    if (e->cfg.sims_per_move < 2 && temp != 0.0)
+    if (e->sims_now < 2 && temp != 0.0)
         return fail(BB_ERR_NAN, "probabilities contain NaN (a fresh root needs >= 2 simulations, MCTS.py:336-338)");
     int rc = check_eval(e);
     if (rc) return rc;
@@ -611,7 +686,7 @@ extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
     HIPCHK(hipSetDevice(e->cfg.device));
     GAME_SWITCH(e->cfg.game, {
         for (int p = 0; p < plies; p++) {
-            int rc = run_sims<G>(e, e->cfg.sims_per_move);
+            int rc = run_sims<G>(e, e->sims_now);
             if (rc) return rc;
             k_selfplay_move<G><<<nblk((size_t)e->dev.n_slots * G::S), 256, 0, e->stream>>>(e->dev);
             HIPCHK(hipGetLastError());

@@ -150,6 +150,13 @@ int bb_load_weights(bb_engine *e, const bb_net_weights *w);
 int bb_get_counters(bb_engine *e, bb_counters *out);
 int bb_reset_counters(bb_engine *e);
 int bb_synchronize(bb_engine *e);
+/* MCTS.PlayLimit can be changed between moves (it is a plain attribute, MCTS.py:116-117). */
+int bb_set_sims_per_move(bb_engine *e, int sims);
+/* Measurement aid: bracket every `every_n`-th evaluator (network) launch with HIP
+ * events on the engine's stream; bb_timing_read synchronises, returns mean/min launch duration in
+ * milliseconds over the recorded launches and clears the record.  every_n = 0 turns it off. */
+int bb_timing_enable(bb_engine *e, int every_n);
+int bb_timing_read(bb_engine *e, double *mean_ms_out, double *min_ms_out, int *count_out);
 
 /* Network.getEvaluation + getPolicy for n positions (Network.py:48-64; graph NetworkFactory.py:22-183).
  * Exactly one of states (packed) / planes (int8 [n][H][W][C], what AsInputArray returns) is non-NULL.
