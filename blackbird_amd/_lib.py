@@ -20,7 +20,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_NAN, ERR_CAPACITY, ERR_WEIGHTS = 0, -1, -2,
 EXPORTS = (
     "bb_game_info_get", "bb_last_error", "bb_device_count", "bb_game_legal", "bb_game_apply", "bb_game_winner",
     "bb_game_encode", "bb_game_initial", "bb_create", "bb_destroy", "bb_load_weights", "bb_get_counters",
-    "bb_reset_counters", "bb_synchronize", "bb_set_sims_per_move", "bb_timing_enable", "bb_timing_read", "bb_net_eval", "bb_hash_eval", "bb_set_roots", "bb_run_sims",
+    "bb_reset_counters", "bb_synchronize", "bb_set_sims_per_move", "bb_timing_enable", "bb_timing_read", "bb_timing_net", "bb_net_eval", "bb_hash_eval", "bb_set_roots", "bb_run_sims",
     "bb_sample_moves", "bb_move_roots", "bb_get_root_states", "bb_selfplay_begin", "bb_selfplay_step",
     "bb_selfplay_done", "bb_examples_fetch", "bb_examples_device",
 )
@@ -87,6 +87,7 @@ def lib():
     L.bb_set_sims_per_move.argtypes = [vp, ip]
     L.bb_timing_enable.argtypes = [vp, ip]
     L.bb_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ip)]
+    L.bb_timing_net.argtypes = [vp, ip, ip, ip, C.POINTER(C.c_double)]
     L.bb_net_eval.argtypes = [vp, ip, vp, vp, vp, vp, vp, ip]
     L.bb_hash_eval.argtypes = [vp, ip, vp, vp, vp]
     L.bb_set_roots.argtypes = [vp, ip, vp, vp, vp]
@@ -297,6 +298,11 @@ class Engine:
         m, mn, c = C.c_double(), C.c_double(), C.c_int()
         check(lib().bb_timing_read(self.h, C.byref(m), C.byref(mn), C.byref(c)))
         return m.value, mn.value, c.value
+
+    def timing_net(self, iters=50, noise=True, ablate=0):
+        ms = C.c_double()
+        check(lib().bb_timing_net(self.h, int(iters), int(noise), int(ablate), C.byref(ms)))
+        return ms.value
 
     def net_eval(self, states=None, planes=None, noise=False):
         A = self.info.A

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -206,7 +207,7 @@ static int engine_alloc(bb_engine *e) {
         dalloc(e, d.eval_policy, n * G::S) || dalloc(e, d.ctr, n * 8) || dalloc(e, d.out_action, n) ||
         dalloc(e, d.out_root_plays, n) || dalloc(e, d.out_child_plays, n * G::S) ||
         dalloc(e, d.out_root_winrate, n) || dalloc(e, d.out_child_value, n * G::S) || dalloc(e, e->d_u, n) ||
-        dalloc(e, e->d_actions, n))
+        dalloc(e, e->d_actions, n) || dalloc(e, d.stamps, 8))
         return BB_ERR_HIP;
     typename G::State *ls;
     if (dalloc(e, ls, n)) return BB_ERR_HIP;
@@ -265,6 +266,11 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     if (cap >= (1 << 26)) return fail(BB_ERR_ARG, "node capacity too large");
     d.node_cap = (int)cap;
     d.example_bytes = e->info.example_bytes;
+    d.gpw = 64 / e->info.S;
+    if (const char *env = getenv("BB_TREE_GPW")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 64 / e->info.S) d.gpw = v;
+    }
     d.temp = 1.0;
     GAME_SWITCH(cfg->game, rc = engine_alloc<G>(e); break);
     if (rc) {
@@ -409,6 +415,7 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     nd.seed = e->cfg.seed;
     nd.alpha = e->cfg.alpha;
     nd.eps = e->cfg.epsilon;
+    nd.dbg = 0;
     e->has_weights = true;
     e->net_F = F;
     e->net_C = C;
@@ -527,7 +534,7 @@ static int launch_eval_inner(bb_engine *e) {
 template <class G>
 static int run_sims(bb_engine *e, int sims) {
     TreeDev &d = e->dev;
-    int tb = nblk((size_t)d.n_slots * G::S);
+    int tb = nblk((size_t)((d.n_slots + d.gpw - 1) / d.gpw) * 64);
     for (int s = 0; s < sims; s++) {
         k_tree_step<G><<<tb, 256, 0, e->stream>>>(d);
         HIPCHK(hipGetLastError());
@@ -695,6 +702,15 @@ extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
     });
 }
 
+#ifdef BB_STAMPS
+extern "C" int bb_debug_stamps(bb_engine *e, unsigned long long *out8) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(out8, e->dev.stamps, 64, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(e->dev.stamps, 0, 64));
+    return BB_OK;
+}
+#endif
+
 static int sum_counters(bb_engine *e, bb_counters *out) {
     size_t n = (size_t)e->dev.n_slots * 8;
     std::vector<uint64_t> h(n);
@@ -773,3 +789,38 @@ extern "C" int bb_examples_device(bb_engine *e, void **ptr_out, uint64_t *bytes_
     if (record_bytes_out) *record_bytes_out = (uint64_t)e->info.example_bytes;
     return BB_OK;
 }
+
+extern "C" int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, double *ms_per_launch_out) {
+    if (!e || iters <= 0) return fail(BB_ERR_ARG, "bad arguments");
+    if (!e->has_weights) return fail(BB_ERR_WEIGHTS, "bb_load_weights has not been called");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    TreeDev &d = e->dev;
+    int saved = e->net.dbg;
+    e->net.dbg = ablate;
+    int rc = BB_OK;
+    GAME_SWITCH(e->cfg.game, {
+        const typename G::State *ls = (const typename G::State *)d.leaf_state;
+        for (int i = 0; i < 3 && !rc; i++)
+            rc = launch_net<G>(e, d.n_slots, ls, nullptr, d.leaf_game_id, d.leaf_serial, noise, d.eval_value, nullptr,
+                               d.eval_policy, G::S, e->stream);
+        HIPCHK(hipEventRecord(a, e->stream));
+        for (int i = 0; i < iters && !rc; i++)
+            rc = launch_net<G>(e, d.n_slots, ls, nullptr, d.leaf_game_id, d.leaf_serial, noise, d.eval_value, nullptr,
+                               d.eval_policy, G::S, e->stream);
+        HIPCHK(hipEventRecord(b, e->stream));
+        break;
+    });
+    e->net.dbg = saved;
+    if (rc) return rc;
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (ms_per_launch_out) *ms_per_launch_out = (double)ms / iters;
+    return BB_OK;
+}
+

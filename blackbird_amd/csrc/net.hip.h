@@ -34,6 +34,7 @@ struct NetDev {
     int off_vk, off_v3, off_d1k, off_d1b, off_d2k, off_d2b, off_pk, off_p6, off_pdk, off_pdb;
     uint64_t seed;
     float alpha, eps;
+    int dbg; // ablation switches for bb_timing_net (0 in production): 1 no heads, 2 no tower, 4 no first conv
 };
 
 template <class G, int PW_>
@@ -136,7 +137,7 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
         }
     }
     // ---- residual tower: 2R convs, K order (tap, r, j) with channel c = 4j + r ---------------------
-    const int L = 2 * nd.R;
+    const int L = (nd.dbg & 2) ? 0 : 2 * nd.R;
     for (int l = 0; l < L; l++) {
         const float *in = (l & 1) ? actB : actA;
         float *out = (l & 1) ? actA : actB;
@@ -174,6 +175,10 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
             }
             if (valid[t]) *(f32x4 *)(out + aoff[t]) = y;
         }
+    }
+    if (nd.dbg & 1) {
+        if (value_out && lane == 0) value_out[pos0] = acc[0][0];
+        return;
     }
     // ---- heads (tower output is in actA; actB and inp are scratch now) --------------------------
     const float *hp = nd.head;
@@ -221,6 +226,14 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
             lg[q] = s;
         }
     }
+    float *nz = lg + PW * A; // [PW][A] Beta(alpha, 1-alpha) draws, one lane per (position, action)
+    if (noise)
+        for (int q = lane; q < PW * A; q += 64) {
+            int pp = q / A, a = q % A, pos = pos0 + pp;
+            if (pos >= n) continue;
+            uint32_t gid = game_id ? game_id[pos] : 0u, ser = serial ? (uint32_t)serial[pos] : (uint32_t)pos;
+            nz[q] = bb_beta_noise(nd.seed, gid, ser, (uint32_t)a, nd.alpha);
+        }
     if (lane < PW && pos0 + lane < n) { // one lane finishes each position (sequential, oracle order)
         const int D = nd.D, pp = lane, pos = pos0 + lane;
         const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
@@ -242,10 +255,9 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
         for (int a = 0; a < A; a++) pr[a] = pr[a] / tot;
         if (noise) { // policy = (1-eps)*softmax + eps*Beta(alpha,1-alpha); policy /= sum(policy)
             float t2 = 0.f;
-            uint32_t gid = game_id ? game_id[pos] : 0u, ser = serial ? (uint32_t)serial[pos] : (uint32_t)pos;
 #pragma unroll
             for (int a = 0; a < A; a++) {
-                pr[a] = (1.0f - nd.eps) * pr[a] + nd.eps * bb_beta_noise(nd.seed, gid, ser, (uint32_t)a, nd.alpha);
+                pr[a] = (1.0f - nd.eps) * pr[a] + nd.eps * nz[pp * A + a];
                 t2 += pr[a];
             }
 #pragma unroll

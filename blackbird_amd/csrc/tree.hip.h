@@ -19,22 +19,36 @@
 #include "games.hip.h"
 #include "rng.hip.h"
 
+// Measured on MI355X (4096 games, 800 sims): touching all 7 children's rows per level makes the
+// descent bandwidth-bound (46 MB/step) and is not faster than the plain dependent row load.
+#ifndef BB_PREFETCH_CHILDREN
+#define BB_PREFETCH_CHILDREN 0
+#endif
 #define NODE_EXPANDED 1
 #define NODE_TERMINAL 2
 #define CHILD_NONE (-1)
 #define CHILD_TERM_BIT 0x40000000
 
+// One node row.  Everything a descent needs from a node sits in the first 128-byte line plus cP
+// (second line); the statistics are kept in the form the PUCT expression consumes them:
+//   Q[i]  = child.WinRate()  (float32 division, refreshed by the backup that changes it)
+//   sq    = sqrt(1.0 + sum(ChildPlays)) (float64, refreshed by the backup)
+//   cP[i] = ExplorationRate * Priors[i] (float64, fixed at expansion)
+// so that one level of _selectAction costs one row load, one float64 multiply, one divide, one add.
 template <class G>
-struct alignas(32) DenseNode {
-    typename G::State st; // 16 B
-    int32_t flags;
-    int32_t nlegal;
+struct alignas(128) DenseNode {
+    int32_t flags;       // NODE_EXPANDED | NODE_TERMINAL | Player << 4 | (winner+1) << 8
     uint32_t legal_mask;
+    int32_t all;         // sum(ChildPlays)
     int32_t serial;
+    double sq;           // sqrt(1.0 + all)
+    double pad0;
     int32_t N[G::S];     // child.Plays
-    float W[G::S];       // child.Value
+    float Q[G::S];       // child.Value / child.Plays (float32), 0 when unvisited
     int32_t child[G::S]; // node index | CHILD_TERM_BIT, or CHILD_NONE
-    double P[G::S];      // Node.Priors
+    alignas(128) double cP[G::S]; // c_puct * Node.Priors
+    float W[G::S];       // child.Value
+    typename G::State st;
 };
 
 struct ExampleHdr { // 16 bytes, then packed state, then u32 visits[S]
@@ -50,6 +64,7 @@ struct TreeDev {
     // configuration
     int n_slots, node_cap, sims_per_move, max_plies, kind, max_depth, evaluator, priors_ones;
     int salt_per_game, max_games;
+    int gpw; // games per 64-lane wave in k_tree_step (latency tuning: fewer games per wave = less SIMT divergence)
     double c_puct;
     uint64_t seed, salt;
     uint32_t first_game_id;
@@ -78,13 +93,32 @@ struct TreeDev {
     int32_t *out_action, *out_root_plays, *out_child_plays;
     float *out_root_winrate, *out_child_value;
     const double *in_u; // optional uniforms
+    unsigned long long *stamps; // diagnostic build only (BB_STAMPS): [apply, fence, select, levels, waves]
 };
 
 // ---- group (G::S lanes) collectives ---------------------------------------------------------
+// Butterfly steps over an 8- or 16-lane group as DPP moves (no LDS round trip):
+// quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror (i <-> 7-i), row_mirror (i <-> 15-i).
+template <int STEP>
+__device__ __forceinline__ int dpp_step_i(int v) {
+    if (STEP == 0) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
+    if (STEP == 1) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
+    if (STEP == 2) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);
+}
+template <int STEP>
+__device__ __forceinline__ double dpp_step_d(double v) {
+    long long b = __double_as_longlong(v);
+    int lo = dpp_step_i<STEP>((int)(b & 0xffffffffll)), hi = dpp_step_i<STEP>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 template <int S>
 __device__ __forceinline__ int grp_sum_i(int v) {
-#pragma unroll
-    for (int o = S / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, S);
+    v += dpp_step_i<0>(v);
+    v += dpp_step_i<1>(v);
+    v += dpp_step_i<2>(v);
+    if (S == 16) v += dpp_step_i<3>(v);
     return v;
 }
 
@@ -112,29 +146,36 @@ __device__ __forceinline__ double grp_np_sum(double x) {
     }
 }
 
-// PUCT argmax over the group's lanes; u < 0 marks lanes that may not be chosen.
-template <int S>
-__device__ __forceinline__ int grp_argmax(double u, int idx) {
-#pragma unroll
-    for (int o = 1; o < S; o <<= 1) {
-        double ou = __shfl_xor(u, o, S);
-        int oi = __shfl_xor(idx, o, S);
-        if (ou > u || (ou == u && oi < idx)) {
-            u = ou;
-            idx = oi;
-        }
+// PUCT argmax over the group's lanes (first maximum wins; u < 0 marks lanes that may not be chosen).
+// `payload` rides along, so every lane ends up with the winner's index AND its child word.
+template <int S, int STEP>
+__device__ __forceinline__ void argmax_step(double &u, int &idx, int &payload) {
+    double ou = dpp_step_d<STEP>(u);
+    int oi = dpp_step_i<STEP>(idx), op = dpp_step_i<STEP>(payload);
+    if (ou > u || (ou == u && oi < idx)) {
+        u = ou;
+        idx = oi;
+        payload = op;
     }
+}
+template <int S>
+__device__ __forceinline__ int grp_argmax(double u, int idx, int &payload) {
+    argmax_step<S, 0>(u, idx, payload);
+    argmax_step<S, 1>(u, idx, payload);
+    argmax_step<S, 2>(u, idx, payload);
+    if (S == 16) argmax_step<S, 3>(u, idx, payload);
     return idx;
 }
 
-template <class G>
-__device__ __forceinline__ double puct_score(const TreeDev &d, int Ni, float Wi, double Pi, int all, bool legal) {
-    double q;
-    if (Ni > 0) q = (d.evaluator == 2) ? (double)Wi / (double)Ni : (double)__fdiv_rn(Wi, (float)Ni);
-    else q = 0.0;
-    double sq = __dsqrt_rn(1.0 + (double)all);
-    double u = q + __ddiv_rn((d.c_puct * Pi) * sq, 1.0 + (double)Ni);
+// U_i = ChildWinRates_i + (ExplorationRate * Priors_i * sqrt(1 + allPlays)) / (1 + ChildPlays_i)   (MCTS.py:327-332)
+__device__ __forceinline__ double puct_score(double q, double cPi, double sq, int Ni, bool legal) {
+    double u = q + __ddiv_rn(cPi * sq, 1.0 + (double)Ni);
     return legal ? u : -1.0;
+}
+// Node.WinRate() of a child: float32 division for float32 evaluators, Python-float division for rollouts
+__device__ __forceinline__ double child_q(const TreeDev &d, float Qi, float Wi, int Ni) {
+    if (d.evaluator != 2) return (double)Qi;
+    return Ni > 0 ? (double)Wi / (double)Ni : 0.0;
 }
 
 // ---- phase A: apply the evaluator's answer for the pending leaf (expand + backup) -------------
@@ -146,7 +187,7 @@ __device__ void phase_apply(const TreeDev &d, int g, int lane) {
     if (leaf < 0) return;
     Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
     Node *node = pool + leaf;
-    typename G::State st = node->st;
+    typename G::State st = ((const typename G::State *)d.leaf_state)[g]; // posted by phase_select
     float v = d.eval_value[g];
     if (d.pend_expand[g]) { // AddChildren with evaluator priors
         uint32_t mask = G::legal_mask(st);
@@ -154,13 +195,15 @@ __device__ void phase_apply(const TreeDev &d, int g, int lane) {
         if (lane < A) x = (double)d.eval_policy[(size_t)g * S + lane] * (double)((mask >> lane) & 1u);
         double tot = grp_np_sum<A, S>(x);
         node->N[lane] = 0;
+        node->Q[lane] = 0.f;
         node->W[lane] = 0.f;
         node->child[lane] = CHILD_NONE;
-        node->P[lane] = (lane < A) ? __ddiv_rn(x, tot) : 0.0;
+        node->cP[lane] = (lane < A) ? d.c_puct * __ddiv_rn(x, tot) : 0.0;
         if (lane == 0) {
             node->flags |= NODE_EXPANDED;
-            node->nlegal = __popc(mask);
             node->legal_mask = mask;
+            node->all = 0;
+            node->sq = 1.0;
         }
     }
     int player = gs_player(st), prev = gs_prev(st);
@@ -178,8 +221,13 @@ __device__ void phase_apply(const TreeDev &d, int g, int lane) {
         uint32_t e = path[k];
         int a = e & 15, pl = (e >> 4) & 3;
         Node *pn = pool + (e >> 6);
-        pn->N[a] += 1;
-        pn->W[a] += (pl == prev) ? v01 : vflip;
+        int n = pn->N[a] + 1, all = pn->all + 1;
+        float w = pn->W[a] + ((pl == prev) ? v01 : vflip);
+        pn->N[a] = n;
+        pn->W[a] = w;
+        pn->Q[a] = __fdiv_rn(w, (float)n);
+        pn->all = all;
+        pn->sq = __dsqrt_rn(1.0 + (double)all);
     }
     if (lane == 0) {
         d.root_N[g] += 1;
@@ -206,9 +254,9 @@ __device__ __forceinline__ int create_child(const TreeDev &d, int g, DenseNode<G
     if (lane == 0) {
         DenseNode<G> *c = pool + idx;
         c->st = st2;
-        c->flags = terminal ? (NODE_TERMINAL | ((w + 1) << 8)) : 0;
-        c->nlegal = 0;
+        c->flags = (terminal ? (NODE_TERMINAL | ((w + 1) << 8)) : 0) | (gs_player(st2) << 4);
         c->legal_mask = 0;
+        c->all = 0;
         c->serial = idx;
         parent->child[a] = word;
         d.n_nodes[g] = idx + 1;
@@ -219,18 +267,20 @@ __device__ __forceinline__ int create_child(const TreeDev &d, int g, DenseNode<G
 
 // MCTS.GetPriors default: ones * LegalActions (MCTS.py:39,346-358).  Returns the legal mask.
 template <class G>
-__device__ __forceinline__ uint32_t expand_ones(DenseNode<G> *node, const typename G::State &st, int lane,
-                                                double &Pi) {
+__device__ __forceinline__ uint32_t expand_ones(const TreeDev &d, DenseNode<G> *node, const typename G::State &st,
+                                                int lane, double &cPi) {
     uint32_t mask = G::legal_mask(st);
-    Pi = (lane < G::A && ((mask >> lane) & 1u)) ? 1.0 : 0.0;
+    cPi = (lane < G::A && ((mask >> lane) & 1u)) ? d.c_puct * 1.0 : 0.0;
     node->N[lane] = 0;
+    node->Q[lane] = 0.f;
     node->W[lane] = 0.f;
     node->child[lane] = CHILD_NONE;
-    node->P[lane] = Pi;
+    node->cP[lane] = cPi;
     if (lane == 0) {
         node->flags |= NODE_EXPANDED;
-        node->nlegal = __popc(mask);
         node->legal_mask = mask;
+        node->all = 0;
+        node->sq = 1.0;
     }
     return mask;
 }
@@ -247,58 +297,90 @@ __device__ void phase_select(const TreeDev &d, int g, int lane) {
     int nn = d.n_nodes[g];
     int depth = 0, expand = 0, overflow = 0, term_leaf = 0;
     const bool inline_expand = d.priors_ones != 0;
-    const bool fixed = d.kind == 1;
+    const bool fixed = d.kind == 1, rollout = d.evaluator == 2;
     typename G::State st;
     int flags = 0;
     bool have = false; // st/flags of `cur` already in registers (node created this simulation)
+    int pf0 = 0, pf1 = 0, spec = 0; // speculative touches of the children's rows (see below)
+#ifdef BB_STAMPS
+    long long acc_load = 0, acc_iter = 0;
+#endif
     for (int it = 0;; it++) {
+#ifdef BB_STAMPS
+        long long ts0 = clock64();
+        acc_iter++;
+#endif
         Node *node = pool + cur;
+        // ONE round trip per level: issue every load of the row together, then wait once.
+        typename G::State st_l = node->st;
+        int flags_l = node->flags;
+        uint32_t mask = node->legal_mask;
+        double sq = node->sq;
+        int Ni = node->N[lane];
+        float Qi = node->Q[lane];
+        float Wi = rollout ? node->W[lane] : 0.f;
+        double cPi = node->cP[lane];
+        int ci = node->child[lane];
+        spec ^= pf0 ^ pf1; // previous level's touches are older than the loads above: no extra stall
+        asm volatile("" ::"v"(flags_l), "v"(mask), "v"(sq), "v"(Ni), "v"(Qi), "v"(cPi), "v"(ci)); // keep them ahead of the branches
+#ifdef BB_STAMPS
+        acc_load += clock64() - ts0;
+#endif
         if (!have) {
-            st = node->st;
-            flags = node->flags;
+            st = st_l;
+            flags = flags_l;
         }
         have = false;
         if (fixed && it >= d.max_depth) break; // FixedMCTS: range(MaxDepth) exhausted
-        uint32_t mask;
-        int Ni, ci;
-        float Wi;
-        double Pi;
         if (!(flags & NODE_EXPANDED)) {
             if (flags & NODE_TERMINAL) { term_leaf = 1; break; } // Winner(lastAction) is not None
             if (!inline_expand) { expand = 1; break; }            // AddChildren once the evaluator has answered
-            mask = expand_ones<G>(node, st, lane, Pi);
+            mask = expand_ones<G>(d, node, st, lane, cPi);
             if (!fixed) break; // DynamicMCTS: AddChildren(node); break
             Ni = 0;
+            Qi = 0.f;
             Wi = 0.f;
+            sq = 1.0;
             ci = CHILD_NONE;
-        } else {
-            mask = node->legal_mask;
-            Ni = node->N[lane];
-            Wi = node->W[lane];
-            Pi = node->P[lane];
-            ci = node->child[lane];
         }
         if (mask == 0) break; // np.sum(LegalActions) == 0
-        int all = grp_sum_i<S>(lane < A ? Ni : 0);
-        double u = puct_score<G>(d, Ni, Wi, Pi, all, lane < A && ((mask >> lane) & 1u));
-        int a = grp_argmax<S>(u, lane);
-        int child = __shfl(ci, a, S);
+        // While the PUCT arithmetic runs, lane i pulls its own child's row towards this CU, so the
+        // next level's (dependent) row load hits cache instead of paying an HBM round trip.
+        pf0 = 0;
+        pf1 = 0;
+        if (BB_PREFETCH_CHILDREN && lane < A && ci >= 0 && !(ci & CHILD_TERM_BIT)) {
+            const int *pc = (const int *)(pool + ci);
+            pf0 = pc[0];
+            pf1 = pc[32];
+        }
+        double u = puct_score(child_q(d, Qi, Wi, Ni), cPi, sq, Ni, lane < A && ((mask >> lane) & 1u));
+        int child = ci;
+        int a = grp_argmax<S>(u, lane, child);
         if (depth >= G::MAXPATH) { overflow = 1; break; }
         if (child == CHILD_NONE) {
             typename G::State st2;
             bool terminal;
             child = create_child<G>(d, g, pool, node, st, a, lane, nn, st2, terminal);
             if (child == CHILD_NONE) { overflow = 1; break; }
-            if (lane == 0) path[depth] = ((uint32_t)cur << 6) | ((uint32_t)gs_player(st) << 4) | (uint32_t)a;
+            if (lane == 0) path[depth] = ((uint32_t)cur << 6) | ((uint32_t)((flags >> 4) & 3) << 4) | (uint32_t)a;
             st = st2;
-            flags = terminal ? NODE_TERMINAL : 0;
+            flags = (terminal ? NODE_TERMINAL : 0) | (gs_player(st2) << 4);
             have = true;
         } else {
-            if (lane == 0) path[depth] = ((uint32_t)cur << 6) | ((uint32_t)gs_player(st) << 4) | (uint32_t)a;
+            if (lane == 0) path[depth] = ((uint32_t)cur << 6) | ((uint32_t)((flags >> 4) & 3) << 4) | (uint32_t)a;
         }
         depth++;
         cur = child & ~CHILD_TERM_BIT;
     }
+#ifdef BB_STAMPS
+    if (d.stamps && lane == 0) {
+        atomicAdd(&d.stamps[5], (unsigned long long)acc_load);
+        atomicAdd(&d.stamps[6], (unsigned long long)acc_iter);
+        atomicAdd(&d.stamps[7], 1ull);
+    }
+#endif
+    spec ^= pf0 ^ pf1;
+    if (spec == 0x5bd1e995 && depth == -7) d.ctr[(size_t)g * 8 + 6] += 1; // never true: keeps the touches alive
     if (lane == 0) {
         ((typename G::State *)d.leaf_state)[g] = st;
         d.leaf_game_id[g] = d.first_game_id + (uint32_t)d.game_lid[g];
@@ -320,11 +402,31 @@ template <class G>
 __global__ void __launch_bounds__(256) k_tree_step(TreeDev d) {
     constexpr int S = G::S;
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    int g = t / S, lane = t % S;
+    int wv = t >> 6, l64 = t & 63;
+    if (l64 >= d.gpw * S) return;
+    int g = wv * d.gpw + l64 / S, lane = l64 % S;
     if (g >= d.n_slots) return;
+#ifdef BB_STAMPS
+    long long t0 = clock64();
+#endif
     phase_apply<G>(d, g, lane);
+#ifdef BB_STAMPS
+    long long t1 = clock64();
+#endif
     __threadfence_block();
+#ifdef BB_STAMPS
+    long long t2 = clock64();
+#endif
     phase_select<G>(d, g, lane);
+#ifdef BB_STAMPS
+    long long t3 = clock64();
+    if ((threadIdx.x & 63) == 0 && d.stamps) {
+        atomicAdd(&d.stamps[0], (unsigned long long)(t1 - t0));
+        atomicAdd(&d.stamps[1], (unsigned long long)(t2 - t1));
+        atomicAdd(&d.stamps[2], (unsigned long long)(t3 - t2));
+        atomicAdd(&d.stamps[4], 1ull);
+    }
+#endif
 }
 
 template <class G>
@@ -360,8 +462,9 @@ __device__ int choose_move(const TreeDev &d, int g, int lane, double temp, doubl
     int all = grp_sum_i<S>(Ni);
     total = all;
     if (temp == 0.0) { // `exploring or temp == 0` -> PUCT argmax (MCTS.py:327-334)
-        double uu = puct_score<G>(d, Ni, Wi, node->P[lane], all, legal);
-        return grp_argmax<S>(uu, lane);
+        double uu = puct_score(child_q(d, node->Q[lane], Wi, Ni), node->cP[lane], node->sq, Ni, legal);
+        int dummy = 0;
+        return grp_argmax<S>(uu, lane, dummy);
     }
     // p_i = N_i^(1/temp) / sum; np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, 'right')
     double it = 1.0 / temp;
@@ -430,7 +533,7 @@ __device__ void advance_root(const TreeDev &d, int g, int lane, int a, typename 
         if (lane == 0) {
             Node *r = pool;
             r->st = new_st;
-            r->flags = 0;
+            r->flags = gs_player(new_st) << 4;
             r->serial = 0;
             d.n_nodes[g] = 1;
             d.root[g] = 0;
@@ -453,7 +556,7 @@ __device__ void advance_root(const TreeDev &d, int g, int lane, int a, typename 
             cw = 0.f;
             if (lane == 0) {
                 pool->st = new_st;
-                pool->flags = 0;
+                pool->flags = gs_player(new_st) << 4;
                 d.n_nodes[g] = 1;
                 d.ctr[(size_t)g * 8 + 6] += 1;
             }
@@ -487,9 +590,9 @@ __device__ __forceinline__ void reset_slot(const TreeDev &d, int g, int lid, con
     using Node = DenseNode<G>;
     Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
     pool->st = st;
-    pool->flags = 0;
-    pool->nlegal = 0;
+    pool->flags = gs_player(st) << 4;
     pool->legal_mask = 0;
+    pool->all = 0;
     pool->serial = 0;
     d.n_nodes[g] = 1;
     d.root[g] = 0;

@@ -157,6 +157,9 @@ int bb_set_sims_per_move(bb_engine *e, int sims);
  * milliseconds over the recorded launches and clears the record.  every_n = 0 turns it off. */
 int bb_timing_enable(bb_engine *e, int every_n);
 int bb_timing_read(bb_engine *e, double *mean_ms_out, double *min_ms_out, int *count_out);
+/* Time `iters` back-to-back launches of the network kernel over the n_slots leaf mailbox (HIP events
+ * on the engine stream); ablate != 0 switches parts of the kernel off (kernel tuning only). */
+int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, double *ms_per_launch_out);
 
 /* Network.getEvaluation + getPolicy for n positions (Network.py:48-64; graph NetworkFactory.py:22-183).
  * Exactly one of states (packed) / planes (int8 [n][H][W][C], what AsInputArray returns) is non-NULL.
