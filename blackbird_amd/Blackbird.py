@@ -1,0 +1,242 @@
+"""Orchestration layer: mirror of /root/reference/src/Blackbird.py.
+
+GenerateTrainingSamples keeps the reference's signature and side effects (one Conn.PutGames per
+game, examples in ply order plus the terminal example, Blackbird.py:219-268) but plays all games
+concurrently on the GPU: every tree, every leaf evaluation and every move runs in the HIP engine
+(bb_selfplay_*); the host only turns finished example records into protobuf blobs.
+"""
+import random
+from collections import defaultdict
+
+import numpy as np
+
+from . import _lib
+from . import proto_wire
+from . import weights as W
+from .MCTS import _seed_from_numpy
+from .DataManager import Connection
+from .DynamicMCTS import DynamicMCTS as MCTS
+from .FixedMCTS import FixedMCTS
+from .Network import Network
+from .NetworkFactory import NetworkFactory
+from .RandomMCTS import RandomMCTS
+
+MAX_CONCURRENT_GAMES = 4096
+
+
+class ExampleState(object):
+    """Blackbird.py:21-81"""
+
+    def __init__(self, evaluation, policy, board, player=None):
+        self.MctsPolicy = policy
+        self.MctsEval = evaluation
+        self.Board = board
+        self.Player = player
+
+    @classmethod
+    def FromSerialized(cls, serialState):
+        f = proto_wire.decode_state(serialState)
+        boardDims = np.frombuffer(f['boardDims'], dtype=np.int8)
+        policyDims = np.frombuffer(f['policyDims'], dtype=np.int8)
+        mctsEval = f['mctsEval'],  # the reference returns a 1-tuple here (trailing comma, Blackbird.py:60)
+        mctsPolicy = np.frombuffer(f['mctsPolicy'], dtype=np.float64)
+        if policyDims.size and int(np.prod(policyDims.astype(np.int64))) == mctsPolicy.size:
+            mctsPolicy = mctsPolicy.reshape(policyDims)
+        board = np.frombuffer(f['boardEncoding'], dtype=np.int8).reshape(boardDims)
+        return cls(mctsEval, mctsPolicy, board)
+
+    def SerializeState(self):
+        pol = np.ascontiguousarray(self.MctsPolicy, dtype=np.float64)
+        # the reference stores dims as int8 (Blackbird.py:76-79): 4032 wraps exactly like old numpy did
+        pdims = np.array(pol.shape, dtype=np.int64).astype(np.int8)
+        return proto_wire.encode_state(0.0 if self.MctsEval is None else self.MctsEval, pol.tobytes(),
+                                       np.ascontiguousarray(self.Board, dtype=np.int8).tobytes(),
+                                       np.array(self.Board.shape, dtype=np.int8).tobytes(), pdims.tobytes())
+
+
+def _records_to_examples(game_cls, rec):
+    """Engine example records -> ExampleState list (s = AsInputArray planes, pi = visits / total, z)."""
+    gi = _lib.game_info(game_cls.GAME_ID)
+    st = np.ascontiguousarray(rec['state']).view(_lib.STATE_DTYPE[game_cls.GAME_ID]).reshape(len(rec), -1)
+    planes = _lib.game_encode(game_cls.GAME_ID, st)
+    out = []
+    for i in range(len(rec)):
+        tot = float(rec['total'][i])
+        visits = rec['visits'][i, :gi.A].astype(np.float64)
+        pi = visits / tot if tot > 0 else np.zeros(gi.A)
+        out.append(ExampleState(float(rec['z'][i]), pi, planes[i:i + 1], player=int(rec['player'][i])))
+    return out
+
+
+def GenerateTrainingSamples(model, nGames, temp):
+    """Blackbird.py:219-268.  Raises ValueError if nGames <= 0."""
+    if nGames <= 0:
+        raise ValueError('Use a positive integer for number of games.')
+    game_cls = model.Game
+    eng = model._selfplay_engine(min(nGames, MAX_CONCURRENT_GAMES), nGames)
+    eng.selfplay_begin(nGames, temp)
+    while not eng.selfplay_done()[0]:
+        eng.selfplay_step(4)
+    if eng.counters()['overflow']:
+        raise _lib.BlackbirdHipError('search tree outgrew the node pool')
+    rec, offs, _win = eng.fetch_examples(0, nGames)
+    for g in range(nGames):
+        examples = _records_to_examples(game_cls, rec[offs[g]:offs[g + 1]])
+        model.Conn.PutGames(model.Name, model.Version, game_cls.GameType, [e.SerializeState() for e in examples])
+
+
+def TrainWithExamples(model, batchSize, learningRate, epochs=1, teacher=None, model_override=None,
+                      version_override=None):
+    """Blackbird.py:271-312"""
+    states = model.Conn.GetGames(model_override if model_override is not None else model.Name,
+                                 version_override if version_override is not None else model.Version)
+    examples = [ExampleState.FromSerialized(state) for state in states]
+    order = np.random.choice(len(examples), len(examples) - (len(examples) % batchSize), replace=False)
+    examples = [examples[i] for i in order]
+    for i in range(len(examples) // batchSize):
+        batch = examples[i * batchSize:(i + 1) * batchSize]
+        model.train(np.vstack([b.Board for b in batch]), np.hstack([b.MctsEval for b in batch]),
+                    np.vstack([b.MctsPolicy for b in batch]), learningRate, teacher)
+    model.Version += 1
+    model.Conn.PutModel(model.Game.GameType, model.Name, model.Version)
+
+
+def TestModels(model1, model2, temp, numTests):
+    """Blackbird.py:177-216: returns 1 / 0 / -1 for model1's win / draw / loss."""
+    for _ in range(numTests):
+        model1ToMove = random.choice([True, False])
+        model1Player = 1 if model1ToMove else 2
+        winner = None
+        model1.DropRoot()
+        model2.DropRoot()
+        state = model1.Game()
+        while winner is None:
+            if model1ToMove:
+                (nextState, *_) = model1.FindMove(state, temp)
+            else:
+                (nextState, *_) = model2.FindMove(state, temp)
+            state = nextState
+            model1.MoveRoot(state)
+            model2.MoveRoot(state)
+            model1ToMove = not model1ToMove
+            winner = state.Winner()
+        if winner == model1Player:
+            return 1
+        elif winner == 0:
+            return 0
+        else:
+            return -1
+
+
+def _tally(model, opponent, temp, numTests, opName, opVersion=0):
+    resultMap = {1: 'wins', 0: 'draws', -1: 'losses'}
+    stats = defaultdict(int)
+    for _ in range(numTests):
+        result = TestModels(model, opponent, temp, numTests=1)
+        stats[resultMap.get(result, 'indeterminant')] += 1
+        model.Conn.PutTrainingStatistic(result, model.Name, model.Version, opName, opVersion)
+    return stats
+
+
+def TestRandom(model, temp, numTests):
+    """Blackbird.py:84-111"""
+    return _tally(model, RandomMCTS(), temp, numTests, 'RANDOM')
+
+
+def TestPrevious(model, temp, numTests):
+    """Blackbird.py:114-143"""
+    oldModel = model.LastVersion()
+    return _tally(model, oldModel, temp, numTests, oldModel.Name, oldModel.Version)
+
+
+def TestGood(model, temp, numTests):
+    """Blackbird.py:146-174"""
+    good = FixedMCTS(maxDepth=10, explorationRate=0.85, timeLimit=1)
+    good.Game = model.Game
+    return _tally(model, good, temp, numTests, 'MCTS')
+
+
+class Model(MCTS, Network):
+    """Blackbird.py:315-389: tree search powered by the network; both halves live in the HIP engine."""
+    _EVALUATOR = _lib.EVAL_NET
+
+    def __init__(self, game, name, mctsConfig, networkConfig={}, tensorflowConfig={}):
+        self.Conn = Connection()
+        self.Game = game
+        self.Name = name
+        self.Version = self.Conn.GetLastVersion(self.Game.GameType, self.Name)
+        self._saveName = self.Name + '_' + str(self.Version)
+        self.MCTSConfig = mctsConfig
+        self.NetworkConfig = networkConfig
+        self.TensorflowConfig = tensorflowConfig
+        MCTS.__init__(self, **mctsConfig)
+        self._batch_engine = None
+        gi = _lib.game_info(game.GAME_ID)
+        if networkConfig != {}:
+            Network.__init__(self, self._saveName,
+                             NetworkFactory(networkConfig, game.LegalMoves, inputShape=(gi.H, gi.W, gi.C)),
+                             tensorflowConfig)
+        else:
+            Network.__init__(self, self._saveName, tensorflowConfig=tensorflowConfig)
+
+    def LastVersion(self):
+        return Model(self.Game, self.Name, self.MCTSConfig, self.NetworkConfig, self.TensorflowConfig)
+
+    # ---- engine plumbing -----------------------------------------------------------------------------------
+    def _make_engine(self, game_id, n_slots, sims, **kw):
+        return _lib.Engine(game_id, n_slots=n_slots, sims_per_move=max(int(sims), 1), mcts_kind=self._KIND,
+                           evaluator=_lib.EVAL_NET, c_puct=float(self.ExplorationRate), noise_on=True,
+                           alpha=float(self.alpha), epsilon=float(self.epsilon),
+                           seed=_seed_from_numpy(), **kw)
+
+    def _after_engine_created(self, engine):
+        gi = engine.info
+        engine.load_weights(W.flatten(self._ensure_weights(gi.C)))
+
+    def _weights_changed(self):
+        Network._weights_changed(self)
+        flat = W.flatten(self._weights)
+        for eng in (self._engine, self._batch_engine):
+            if eng is not None:
+                eng.load_weights(flat)
+        self.SampleValue.cache_clear()
+        self.GetPriors.cache_clear()
+
+    def _selfplay_engine(self, n_slots, n_games):
+        if self.PlayLimit is None:
+            raise ValueError('Not enough information to decide a stop time.')
+        eng = self._batch_engine
+        if eng is None or eng.n_slots != n_slots or eng.cfg.max_games < n_games:
+            if eng is not None:
+                eng.close()
+            eng = self._make_engine(self.Game.GAME_ID, n_slots, self.PlayLimit, max_games=n_games)
+            eng.load_weights(W.flatten(self._ensure_weights(eng.info.C)))
+            self._batch_engine = eng
+        return eng
+
+    # ---- Model overrides (Blackbird.py:350-389), kept for callers that use them directly ---------------------
+    class _Cached(object):
+        def __init__(self, fn):
+            self._fn = fn
+
+        def __get__(self, obj, objtype=None):
+            import functools
+            bound = functools.partial(self._fn, obj)
+            bound.cache_clear = lambda: None  # evaluations are not memoised on the host
+            return bound
+
+    def _sample_value(self, state, player):
+        value = self.getEvaluation(state.AsInputArray())
+        value = (value + 1) * 0.5
+        if state.Player != player:
+            value = 1 - value
+        assert value >= 0, 'Value: {}'.format(value)
+        return value
+
+    def _get_priors(self, state):
+        policy = self.getPolicy(state.AsInputArray()) * state.LegalActions()
+        policy /= np.sum(policy)
+        return policy
+
+    SampleValue = _Cached(_sample_value)
+    GetPriors = _Cached(_get_priors)

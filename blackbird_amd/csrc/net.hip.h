@@ -231,7 +231,7 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
         for (int q = lane; q < PW * A; q += 64) {
             int pp = q / A, a = q % A, pos = pos0 + pp;
             if (pos >= n) continue;
-            uint32_t gid = game_id ? game_id[pos] : 0u, ser = serial ? (uint32_t)serial[pos] : (uint32_t)pos;
+            uint32_t gid = game_id ? game_id[pos] : (uint32_t)noise, ser = serial ? (uint32_t)serial[pos] : (uint32_t)pos;
             nz[q] = bb_beta_noise(nd.seed, gid, ser, (uint32_t)a, nd.alpha);
         }
     if (lane < PW && pos0 + lane < n) { // one lane finishes each position (sequential, oracle order)

@@ -164,7 +164,9 @@ int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, double *ms_per
 /* Network.getEvaluation + getPolicy for n positions (Network.py:48-64; graph NetworkFactory.py:22-183).
  * Exactly one of states (packed) / planes (int8 [n][H][W][C], what AsInputArray returns) is non-NULL.
  * value_out[n] tanh value for the side to move; logits_out[n][A] pre-softmax; policy_out[n][A]
- * softmax, mixed with Beta noise and re-normalised when noise != 0.  Outputs may be NULL. */
+ * softmax, mixed with Beta noise and re-normalised when noise != 0 (the value of `noise` selects the
+ * random stream, so successive calls can draw fresh noise like successive sess.run calls do).
+ * Outputs may be NULL. */
 int bb_net_eval(bb_engine *e, int n, const void *states, const int8_t *planes, float *value_out,
                 float *logits_out, float *policy_out, int noise);
 /* the validation evaluator, same outputs (policy unnormalised, as getPolicy-shaped input to GetPriors) */
