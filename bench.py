@@ -88,8 +88,10 @@ def main():
     total_plies = args.prefill + Wm + K + 2
     # every slot finishes at most one game per 7 plies (shortest Connect4 game)
     max_games = args.slots * (total_plies // 7 + 2)
+    from blackbird_amd import dist as bdist
+    first_id, seed = bdist.shard(rank, 1234)
     eng = _lib.Engine(game, n_slots=args.slots, sims_per_move=args.sims, evaluator=_lib.EVAL_NET, c_puct=0.85,
-                      seed=1234 + rank, first_game_id=rank * 50_000_000, noise_on=True, alpha=0.2, epsilon=0.3,
+                      seed=seed, first_game_id=first_id, noise_on=True, alpha=0.2, epsilon=0.3,
                       device=local, max_games=max_games)
     eng.load_weights(flat)
     eng.selfplay_begin(max_games, 1.0)
@@ -127,24 +129,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         games, sims, plies = [float(x) for x in t[:3].tolist()]
         dt = float(tmax[3])
-        # epoch-end exchange: all-gather the examples generated in the timed region
-        done_flags = np.zeros(1)
+        # epoch-end exchange: all-gather the finished games' (s, pi, z) records over RCCL
+        from blackbird_amd import dist as bdist
         rec, offs, win = eng.fetch_examples(0, max_games)
-        payload = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
-        n_local = torch.tensor([payload.numel()], device="cuda", dtype=torch.int64)
-        sizes = [torch.zeros_like(n_local) for _ in range(world)]
-        dist.all_gather(sizes, n_local)
-        mx = int(max(int(s) for s in sizes))
-        pad = torch.zeros(mx, dtype=torch.uint8, device="cuda")
-        pad[:payload.numel()] = payload
-        gathered = [torch.empty_like(pad) for _ in range(world)]
         tg = time.perf_counter()
-        dist.all_gather(gathered, pad)
+        allrec = bdist.allgather_records(rec, device=f"cuda:{local}")
         torch.cuda.synchronize()
         allgather_s = time.perf_counter() - tg
-        del done_flags
+        n_examples_all = int(len(allrec))
     else:
         allgather_s = None
+        n_examples_all = None
 
     if rank == 0:
         evals_per_launch = args.slots
@@ -167,6 +162,7 @@ def main():
         }
         if allgather_s is not None:
             out["examples_allgather_s"] = allgather_s
+            out["examples_gathered"] = n_examples_all
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
