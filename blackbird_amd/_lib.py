@@ -142,7 +142,7 @@ def game_info(game):
 
 # ---- packed states (layout: include/blackbird_hip.h) -------------------------------------------------
 GRID = {GAME_CONNECT4: (6, 7, 8), GAME_TICTACTOE: (3, 3, 4)}  # H, W, bit stride
-STATE_DTYPE = {GAME_CONNECT4: np.dtype("<u8"), GAME_TICTACTOE: np.dtype("<u8")}
+STATE_DTYPE = {GAME_CONNECT4: np.dtype("<u8"), GAME_TICTACTOE: np.dtype("<u8"), GAME_DRAGONCHESS: np.dtype("u1")}
 
 
 def pack_grid(game, boards, players, prevs=None):
@@ -177,6 +177,25 @@ def unpack_grid(game, packed):
     players = ((packed[:, 0] >> np.uint64(56)) & np.uint64(3)).astype(np.int8)
     prevs = ((packed[:, 0] >> np.uint64(58)) & np.uint64(3)).astype(np.int8)
     return boards, players, prevs
+
+
+def pack_dc(boards, players, prevs=None, castles=None):
+    """boards [n,8,8] piece codes, players [n], prevs [n] (0 == None), castles [n,4] -> uint8 [n,80]."""
+    boards = np.asarray(boards).reshape(-1, 64)
+    n = boards.shape[0]
+    out = np.zeros((n, 80), dtype=np.uint8)
+    out[:, :64] = boards.astype(np.int8).view(np.uint8)
+    out[:, 64] = np.asarray(players, dtype=np.uint8).reshape(n)
+    out[:, 65] = 0 if prevs is None else np.asarray(prevs, dtype=np.uint8).reshape(n)
+    if castles is not None:
+        out[:, 66:70] = (np.asarray(castles).reshape(n, 4) != 0).astype(np.uint8)
+    return out
+
+
+def unpack_dc(packed):
+    packed = np.asarray(packed, dtype=np.uint8).reshape(-1, 80)
+    boards = packed[:, :64].view(np.int8).reshape(-1, 8, 8).copy()
+    return boards, packed[:, 64].astype(np.int8), packed[:, 65].astype(np.int8), packed[:, 66:70].astype(np.int8)
 
 
 # ---- stateless batched game ops --------------------------------------------------------------------
@@ -220,7 +239,7 @@ def game_initial(game):
     gi = game_info(game)
     buf = np.zeros(gi.state_bytes, dtype=np.uint8)
     check(lib().bb_game_initial(game, ptr(buf)))
-    return buf.view(STATE_DTYPE[game]).reshape(1, -1) if game in STATE_DTYPE else buf.reshape(1, -1)
+    return buf.view(STATE_DTYPE[game]).reshape(1, -1)
 
 
 def example_dtype(game):
@@ -355,7 +374,7 @@ class Engine:
     def root_states(self):
         buf = np.zeros((self.n_slots, self.info.state_bytes), dtype=np.uint8)
         check(lib().bb_get_root_states(self.h, ptr(buf)))
-        return buf.view(STATE_DTYPE[self.game]) if self.game in STATE_DTYPE else buf
+        return buf.view(STATE_DTYPE[self.game])
 
     def selfplay_begin(self, n_games, temp):
         check(lib().bb_selfplay_begin(self.h, int(n_games), float(temp)))

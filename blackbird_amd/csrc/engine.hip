@@ -57,6 +57,11 @@ extern "C" int bb_game_info_get(int game, bb_game_info *out) {
     switch (game) {
     case BB_GAME_CONNECT4: fill_info<Connect4>(out); return BB_OK;
     case BB_GAME_TICTACTOE: fill_info<TicTacToe>(out); return BB_OK;
+    case BB_GAME_DRAGONCHESS:
+        fill_info<DragonChess>(out);
+        out->dense = 0;
+        out->example_bytes = (int)(sizeof(ExampleHdr) + sizeof(DCState) + 4 * DragonChess::S + 2 * DragonChess::S);
+        return BB_OK;
     default: return fail(BB_ERR_ARG, "unknown or unsupported game %d", game);
     }
 }
@@ -81,7 +86,10 @@ static int game_legal(int n, const void *states, uint8_t *out) {
     DevBuf ds, dout;
     if (ds.alloc((size_t)n * sizeof(typename G::State)) || dout.alloc((size_t)n * G::A)) return BB_ERR_HIP;
     HIPCHK(hipMemcpy(ds.p, states, (size_t)n * sizeof(typename G::State), hipMemcpyDefault));
-    k_game_legal<G><<<nblk(n), 256>>>(n, (const typename G::State *)ds.p, (uint8_t *)dout.p);
+    if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+        k_dc_legal<<<nblk((size_t)n * 64), 256>>>(n, (const DCState *)ds.p, (uint8_t *)dout.p);
+    else
+        k_game_legal<G><<<nblk(n), 256>>>(n, (const typename G::State *)ds.p, (uint8_t *)dout.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, dout.p, (size_t)n * G::A, hipMemcpyDefault));
     return BB_OK;
@@ -118,7 +126,10 @@ static int game_encode(int n, const void *states, int8_t *out) {
     DevBuf ds, dout;
     if (ds.alloc((size_t)n * sizeof(typename G::State)) || dout.alloc(ob)) return BB_ERR_HIP;
     HIPCHK(hipMemcpy(ds.p, states, (size_t)n * sizeof(typename G::State), hipMemcpyDefault));
-    k_game_encode<G><<<nblk((size_t)n * G::H * G::W), 256>>>(n, (const typename G::State *)ds.p, (int8_t *)dout.p);
+    if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+        k_dc_encode<<<nblk((size_t)n * 64), 256>>>(n, (const DCState *)ds.p, (int8_t *)dout.p);
+    else
+        k_game_encode<G><<<nblk((size_t)n * G::H * G::W), 256>>>(n, (const typename G::State *)ds.p, (int8_t *)dout.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, dout.p, ob, hipMemcpyDefault));
     return BB_OK;
@@ -131,25 +142,33 @@ static int game_encode(int n, const void *states, int8_t *out) {
     default: return fail(BB_ERR_ARG, "unknown or unsupported game %d", game);    \
     }
 
+#define GAME_SWITCH_ALL(game, ...)                                               \
+    switch (game) {                                                              \
+    case BB_GAME_CONNECT4: { using G = Connect4; __VA_ARGS__; }                  \
+    case BB_GAME_TICTACTOE: { using G = TicTacToe; __VA_ARGS__; }                \
+    case BB_GAME_DRAGONCHESS: { using G = DragonChess; __VA_ARGS__; }            \
+    default: return fail(BB_ERR_ARG, "unknown game %d", game);                   \
+    }
+
 extern "C" int bb_game_legal(int game, int n, const void *states, uint8_t *legal_out) {
     if (n <= 0 || !states || !legal_out) return fail(BB_ERR_ARG, "bad arguments");
-    GAME_SWITCH(game, return game_legal<G>(n, states, legal_out));
+    GAME_SWITCH_ALL(game, return game_legal<G>(n, states, legal_out));
 }
 extern "C" int bb_game_apply(int game, int n, void *states, const int32_t *actions, int32_t *status_out) {
     if (n <= 0 || !states || !actions) return fail(BB_ERR_ARG, "bad arguments");
-    GAME_SWITCH(game, return game_apply<G>(n, states, actions, status_out));
+    GAME_SWITCH_ALL(game, return game_apply<G>(n, states, actions, status_out));
 }
 extern "C" int bb_game_winner(int game, int n, const void *states, const int32_t *prev, int8_t *winner_out) {
     if (n <= 0 || !states || !winner_out) return fail(BB_ERR_ARG, "bad arguments");
-    GAME_SWITCH(game, return game_winner<G>(n, states, prev, winner_out));
+    GAME_SWITCH_ALL(game, return game_winner<G>(n, states, prev, winner_out));
 }
 extern "C" int bb_game_encode(int game, int n, const void *states, int8_t *planes_out) {
     if (n <= 0 || !states || !planes_out) return fail(BB_ERR_ARG, "bad arguments");
-    GAME_SWITCH(game, return game_encode<G>(n, states, planes_out));
+    GAME_SWITCH_ALL(game, return game_encode<G>(n, states, planes_out));
 }
 extern "C" int bb_game_initial(int game, void *state_out) {
     if (!state_out) return fail(BB_ERR_ARG, "null out");
-    GAME_SWITCH(game, {
+    GAME_SWITCH_ALL(game, {
         typename G::State s = G::initial();
         memcpy(state_out, &s, sizeof s);
         return BB_OK;

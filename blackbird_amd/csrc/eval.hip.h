@@ -9,7 +9,6 @@ __global__ void __launch_bounds__(256) k_game_legal(int n, const typename G::Sta
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t m = G::legal_mask(st[i]);
-#pragma unroll
     for (int a = 0; a < G::A; a++) out[(size_t)i * G::A + a] = (m >> a) & 1u;
 }
 
@@ -105,4 +104,53 @@ __global__ void __launch_bounds__(256) k_rollout(int n, const typename G::State 
         w = G::winner(s, a);
     }
     value[i] = w == 0 ? 0.5f : (player == w ? 1.0f : 0.0f);
+}
+
+// ---- DragonChess batched kernels ---------------------------------------------------------------------
+// LegalActions (DragonChess.py:78-106): one wave per board, lane = from-square; each lane emits its 63
+// contiguous mask bytes (action id = sq1*63 + sq2 - (sq2 > sq1)).
+__global__ void __launch_bounds__(256) k_dc_legal(int n, const DCState *st, uint8_t *out) {
+    int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= n) return;
+    DCState s = st[w];
+    uint64_t m = DragonChess::targets(s, lane);
+    uint8_t *o = out + (size_t)w * 4032 + lane * 63;
+    for (int sq2 = 0, k = 0; sq2 < 64; sq2++) {
+        if (sq2 == lane) continue;
+        o[k++] = (uint8_t)((m >> sq2) & 1);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_dc_encode(int n, const DCState *st, int8_t *out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * 64) return;
+    int i = (int)(t >> 6), c = (int)(t & 63);
+    int8_t v[17];
+    DragonChess::encode_cell(st[i], c >> 3, c & 7, v);
+    int8_t *o = out + t * 17;
+    for (int k = 0; k < 17; k++) o[k] = v[k];
+}
+
+// validation evaluator for DragonChess: one wave per leaf (FNV chain on lane 0, 4032 policy hashes spread over lanes)
+__global__ void __launch_bounds__(256) k_dc_hash_eval(int n, const DCState *st, const uint32_t *game_id, uint64_t salt,
+                                                      int salt_per_game, uint32_t first_game_id, float *value,
+                                                      float *policy, int pstride) {
+    int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= n) return;
+    uint64_t z = 0;
+    if (lane == 0) {
+        DCState s = st[w];
+        uint64_t sl = salt + ((salt_per_game && game_id) ? (uint64_t)(game_id[w] - first_game_id) : 0ull);
+        HashAcc h(sl);
+        for (int c = 0; c < 64; c++) {
+            int8_t v[17];
+            DragonChess::encode_cell(s, c >> 3, c & 7, v);
+            for (int k = 0; k < 17; k++) h.byte(v[k]);
+        }
+        z = h.final();
+        if (value) value[w] = bb_hash_value(z);
+    }
+    z = __shfl(z, 0, 64);
+    if (policy)
+        for (int a = lane; a < 4032; a += 64) policy[(size_t)w * pstride + a] = bb_hash_policy(z, a);
 }

@@ -166,3 +166,206 @@ struct GridGame {
 
 using Connect4 = GridGame<6, 7, 4, 8, 7, 8, 0>;
 using TicTacToe = GridGame<3, 3, 3, 4, 9, 16, 1>;
+
+// ------------------------------------------------------------------------------------------------
+// DragonChess (DragonChess.py:10-371): White = K + 3 pawns and moves twice per turn, Black = full army,
+// win by capturing the king.  Pseudo-legal rules exactly as the reference codes them: promotions
+// and castling return Python 0 (falsy) => pawns on their 7th rank cannot advance and castling is
+// never legal; no en passant; no check rule.  Packed state = 80 B (include/blackbird_hip.h).
+// ------------------------------------------------------------------------------------------------
+struct alignas(16) DCState {
+    int8_t b[64]; // row*8+col, signed codes K1 P2 N3 B4 R5 Q6, row 0 = White's back rank
+    int8_t player, prev;
+    int8_t castle[4]; // wK wQ bK bQ
+    int8_t pad[10];
+};
+static_assert(sizeof(DCState) == 80, "packed DragonChess state is 80 bytes");
+
+struct DragonChess {
+    static constexpr int H = 8, W = 8, C = 17, A = 4032, S = 144, GID = 2;
+    static constexpr int MAXPATH = 128;
+    using State = DCState;
+
+    BB_HD static State initial() { // fen 'rnbqkbnr/pppppppp/8/8/8/8/3PPP2/4K3 w kq' (DragonChess.py:36-60)
+        State s;
+        for (int i = 0; i < 64; i++) s.b[i] = 0;
+        const int8_t back[8] = {-5, -3, -4, -6, -1, -4, -3, -5};
+        for (int c = 0; c < 8; c++) {
+            s.b[56 + c] = back[c];
+            s.b[48 + c] = -2;
+        }
+        s.b[8 + 3] = 2;
+        s.b[8 + 4] = 2;
+        s.b[8 + 5] = 2;
+        s.b[4] = 1;
+        s.player = 1;
+        s.prev = 0;
+        s.castle[0] = 0;
+        s.castle[1] = 0;
+        s.castle[2] = 1;
+        s.castle[3] = 1;
+        for (int i = 0; i < 10; i++) s.pad[i] = 0;
+        return s;
+    }
+    BB_HD static int iabs(int x) { return x < 0 ? -x : x; }
+    BB_HD static int isgn(int x) { return (x > 0) - (x < 0); }
+
+    // _is_legal_move(loc, new) with promote=None, castle=None (DragonChess.py:242-371)
+    BB_HD static bool is_legal(const int8_t *b, int player, int lr, int lc, int nr, int nc) {
+        int piece = b[lr * 8 + lc], target = b[nr * 8 + nc];
+        // _sanity_check :242-259
+        if (nr == lr && nc == lc) return false;
+        if (piece > 0) {
+            if (target > 0) return false;
+        } else {
+            if (target < 0) return false;
+        }
+        if (piece < 0 && player == 1) return false;
+        if (piece > 0 && player == 2) return false;
+        if (piece == 0) return false;
+        int adr = iabs(lr - nr), adc = iabs(lc - nc);
+        switch (iabs(piece)) {
+        case 1: return adr <= 1 && adc <= 1; // castling branches return 0 (:356-363)
+        case 2: // pawn :282-319
+            if (piece > 0) {
+                if (lr == 6 && lc == nc && nr == 7 && b[56 + nc] == 0) return false;          // promotion -> 0
+                else if (lr == 6 && adc == 1 && nr == 7 && b[56 + nc] < 0) return false;      // capture-promotion -> 0
+                else if (lr == 1) {
+                    if (lc == nc) {
+                        if (nr == 3 && b[24 + nc] == 0 && b[16 + nc] == 0) return true;
+                        else if (nr == 2 && b[16 + nc] == 0) return true;
+                        return false;
+                    }
+                } else if (lr > 1 && lr < 6) {
+                    if (lc == nc && target == 0 && nr == lr + 1) return true;
+                }
+                if (adc == 1 && nr == lr + 1 && target < 0) return true;
+            } else {
+                if (lr == 1 && lc == nc && nr == 0 && b[nc] == 0) return false;
+                else if (lr == 1 && adc == 1 && nr == 0 && b[nc] > 0) return false;
+                else if (lr == 6) {
+                    if (lc == nc) {
+                        if (nr == 4 && b[32 + nc] == 0 && b[40 + nc] == 0) return true;
+                        else if (nr == 5 && b[40 + nc] == 0) return true;
+                        return false;
+                    }
+                } else if (lr > 1 && lr < 6) {
+                    if (lc == nc && target == 0 && nr == lr - 1) return true;
+                }
+                if (adc == 1 && nr == lr - 1 && target > 0) return true;
+            }
+            return false;
+        case 3: return (adr == 1 && adc == 2) || (adr == 2 && adc == 1);
+        case 4: return bishop(b, lr, lc, nr, nc);
+        case 5: return rook(b, lr, lc, nr, nc);
+        case 6: return bishop(b, lr, lc, nr, nc) || rook(b, lr, lc, nr, nc);
+        }
+        return false;
+    }
+    BB_HD static bool rook(const int8_t *b, int lr, int lc, int nr, int nc) { // :321-339
+        if (!(nr == lr || nc == lc)) return false;
+        if (nr == lr) {
+            int lo = nc < lc ? nc : lc, hi = nc < lc ? lc : nc;
+            for (int c = lo + 1; c < hi; c++)
+                if (b[nr * 8 + c] != 0) return false;
+        } else {
+            int lo = nr < lr ? nr : lr, hi = nr < lr ? lr : nr;
+            for (int r = lo + 1; r < hi; r++)
+                if (b[r * 8 + nc] != 0) return false;
+        }
+        return true;
+    }
+    BB_HD static bool bishop(const int8_t *b, int lr, int lc, int nr, int nc) { // :341-347
+        if (iabs(lr - nr) != iabs(lc - nc)) return false;
+        int sr = isgn(nr - lr), sc = isgn(nc - lc);
+        for (int d = 1; d < iabs(lr - nr); d++)
+            if (b[(lr + d * sr) * 8 + (lc + d * sc)] != 0) return false;
+        return true;
+    }
+
+    // legal targets of one from-square as a 64-bit mask (bit = to-square)
+    BB_HD static uint64_t targets(const State &s, int sq1) {
+        uint64_t m = 0;
+        int piece = s.b[sq1];
+        if (piece == 0 || (piece < 0 && s.player == 1) || (piece > 0 && s.player == 2)) return 0;
+        for (int sq2 = 0; sq2 < 64; sq2++)
+            if (sq2 != sq1 && is_legal(s.b, s.player, sq1 >> 3, sq1 & 7, sq2 >> 3, sq2 & 7)) m |= 1ull << sq2;
+        return m;
+    }
+    BB_HD static int action_id(int sq1, int sq2) { return sq1 * 63 + sq2 - (sq2 > sq1); } // DragonChess.py:26-34
+    BB_HD static void action_squares(int a, int &sq1, int &sq2) {
+        sq1 = a / 63;
+        int rem = a % 63;
+        sq2 = rem + (rem >= sq1);
+    }
+
+    // ApplyAction (:127-159) + Move (:172-214) for action < 4032; false == ValueError
+    BB_HD static bool apply(State &s, int a) {
+        if (a < 0 || a >= A) return false;
+        int sq1, sq2;
+        action_squares(a, sq1, sq2);
+        if (!is_legal(s.b, s.player, sq1 >> 3, sq1 & 7, sq2 >> 3, sq2 & 7)) return false;
+        s.b[sq2] = s.b[sq1];
+        s.b[sq1] = 0;
+        if (s.prev == 1 && s.player == 1) { // :192-197: W, W, B, W, W, B ...
+            s.player = 2;
+            s.prev = 1;
+        } else {
+            s.prev = s.player;
+            s.player = 1;
+        }
+        if (s.b[4] != 1) { // :199-212
+            s.castle[0] = 0;
+            s.castle[1] = 0;
+        } else if (s.b[7] != 5) {
+            s.castle[0] = 0;
+        }
+        if (s.b[0] != 5) s.castle[1] = 0;
+        if (s.b[60] != -1) {
+            s.castle[2] = 0;
+            s.castle[3] = 0;
+        } else if (s.b[63] != -5) {
+            s.castle[2] = 0;
+        }
+        if (s.b[56] != -5) s.castle[3] = 0;
+        return true;
+    }
+
+    BB_HD static int winner(const State &s, int /*prev*/) { // :161-167
+        bool bk = false, wk = false;
+        for (int i = 0; i < 64; i++) {
+            bk |= s.b[i] == -1;
+            wk |= s.b[i] == 1;
+        }
+        if (!bk) return 1;
+        if (!wk) return 2;
+        return -1;
+    }
+
+    // AsInputArray cell -> 17 planes (:111-125, piece_map :11)
+    BB_HD static void encode_cell(const State &s, int r, int c, int8_t out[17]) {
+        for (int k = 0; k < 17; k++) out[k] = 0;
+        int v = s.b[r * 8 + c];
+        int plane = -1;
+        switch (v) {
+        case 1: plane = 10; break;
+        case -1: plane = 11; break;
+        case 2: plane = 0; break;
+        case -2: plane = 1; break;
+        case 3: plane = 4; break;
+        case -3: plane = 5; break;
+        case 4: plane = 6; break;
+        case -4: plane = 7; break;
+        case 5: plane = 2; break;
+        case -5: plane = 3; break;
+        case 6: plane = 8; break;
+        case -6: plane = 9; break;
+        }
+        if (plane >= 0) out[plane] = 1;
+        out[12] = s.castle[0];
+        out[13] = s.castle[1];
+        out[14] = s.castle[2];
+        out[15] = s.castle[3];
+        out[16] = (s.player == 1 && s.prev == 1) ? 1 : 0;
+    }
+};

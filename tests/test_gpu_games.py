@@ -130,3 +130,79 @@ def test_full_size_properties():
     b, _p, _v = _lib.unpack_grid(game, st)
     assert np.array_equal(b.sum((1, 2, 3)), plies)  # one stone per ply
     assert (b.sum(3) <= 1).all()
+
+
+# ---- DragonChess ---------------------------------------------------------------------------------------
+def _pack_dc(g):
+    return _lib.pack_dc(g["board"].reshape(-1, 8, 8), g["player"], g["prev"], g["castle"])
+
+
+def test_dc_golden_random_boards(golden_dir):
+    game = _lib.GAME_DRAGONCHESS
+    g = _load(golden_dir, "boards_dc.npz")
+    st = _pack_dc(g)
+    n = st.shape[0]
+    assert np.array_equal(_lib.game_legal(game, st), _legal_dense(g, n, 4032))
+    assert np.array_equal(_lib.game_winner(game, st), g["win_none"].astype(np.int8))
+    assert np.array_equal(_lib.game_encode(game, st).reshape(n, -1), g["enc"])
+    ap = g["apply_ok"]  # [n][32][72]: action, ok, player, prev, castle[4], board[64]
+    for k in range(ap.shape[1]):
+        acts = ap[:, k, 0].astype(np.int32)
+        sel = acts >= 0
+        nxt, status = _lib.game_apply(game, st[sel], acts[sel])
+        assert np.array_equal(status == 0, ap[sel, k, 1] == 1)
+        ok = status == 0
+        b, p, pv, cs = _lib.unpack_dc(nxt[ok])
+        want = ap[sel][ok][:, k]
+        assert np.array_equal(p, want[:, 2]) and np.array_equal(pv, want[:, 3])
+        assert np.array_equal(cs, want[:, 4:8]) and np.array_equal(b.reshape(-1, 64), want[:, 8:72])
+        assert np.array_equal(nxt[~ok], st[sel][~ok])
+
+
+def test_dc_golden_playouts(golden_dir):
+    game = _lib.GAME_DRAGONCHESS
+    g = _load(golden_dir, "playouts_dc.npz")
+    st = _pack_dc(g)
+    n = st.shape[0]
+    assert np.array_equal(_lib.game_legal(game, st), _legal_dense(g, n, 4032))
+    assert np.array_equal(_lib.game_winner(game, st), g["win_none"].astype(np.int8))
+    assert np.array_equal(_lib.game_encode(game, st).reshape(n, -1), g["enc"])
+    mv = np.where(g["action"] >= 0)[0]
+    nxt, status = _lib.game_apply(game, st[mv], g["action"][mv])
+    assert (status == 0).all() and np.array_equal(nxt, st[mv + 1])  # incl. W,W,B turn order and castle flags
+    assert np.array_equal(_lib.game_winner(game, nxt, g["action"][mv]), g["win_prev"][mv].astype(np.int8))
+    # initial position and the start-position move list
+    init = _lib.game_initial(game)
+    assert np.array_equal(init, st[:1])
+    la = np.where(_lib.game_legal(game, init)[0] == 1)[0]
+    assert [(a // 63, (a % 63) + ((a % 63) >= a // 63)) for a in la] == \
+        [(4, 3), (4, 5), (11, 19), (11, 27), (12, 20), (12, 28), (13, 21), (13, 29)]
+
+
+def test_dc_random_games_vs_oracle(orc):
+    """2048 random DragonChess games advanced in lock-step on the GPU; every 16th game is replayed on the oracle."""
+    game = _lib.GAME_DRAGONCHESS
+    n = 2048
+    rng = np.random.RandomState(17)
+    st = np.repeat(_lib.game_initial(game), n, axis=0)
+    alive = np.ones(n, dtype=bool)
+    ost = {i: orc.new_state(2) for i in range(0, n, 16)}
+    for ply in range(60):
+        legal = _lib.game_legal(game, st)
+        cnt = legal.sum(1)
+        assert (cnt[alive] > 0).all()
+        pick = (rng.rand(n, 4032).astype(np.float32) * legal).argmax(1).astype(np.int32)
+        nxt, status = _lib.game_apply(game, st, pick)
+        assert (status[alive] == 0).all()
+        for i, s in ost.items():
+            if not alive[i]:
+                continue
+            assert np.array_equal(np.where(orc.legal(2, s) == 1)[0], np.where(legal[i] == 1)[0])
+            assert orc.apply(2, s, int(pick[i])) == 0
+            b, p, pv, cs = _lib.unpack_dc(nxt[i:i + 1])
+            assert bytes(s.b)[:64] == b.tobytes() and s.player == p[0] and s.prev == pv[0] and list(s.castle) == list(cs[0])
+        w = _lib.game_winner(game, nxt)
+        st = np.where(alive[:, None], nxt, st)
+        alive &= w < 0
+    b, _p, _pv, _cs = _lib.unpack_dc(st)
+    assert ((b == 1).sum((1, 2)) <= 1).all() and ((b == -1).sum((1, 2)) <= 1).all()
