@@ -6,6 +6,7 @@
 #include "eval.hip.h"
 #include "net.hip.h"
 #include "tree.hip.h"
+#include "tree_dc.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -13,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 static thread_local std::string g_err;
@@ -139,16 +141,10 @@ static int game_encode(int n, const void *states, int8_t *out) {
     switch (game) {                                                              \
     case BB_GAME_CONNECT4: { using G = Connect4; __VA_ARGS__; }                  \
     case BB_GAME_TICTACTOE: { using G = TicTacToe; __VA_ARGS__; }                \
-    default: return fail(BB_ERR_ARG, "unknown or unsupported game %d", game);    \
-    }
-
-#define GAME_SWITCH_ALL(game, ...)                                               \
-    switch (game) {                                                              \
-    case BB_GAME_CONNECT4: { using G = Connect4; __VA_ARGS__; }                  \
-    case BB_GAME_TICTACTOE: { using G = TicTacToe; __VA_ARGS__; }                \
     case BB_GAME_DRAGONCHESS: { using G = DragonChess; __VA_ARGS__; }            \
     default: return fail(BB_ERR_ARG, "unknown game %d", game);                   \
     }
+#define GAME_SWITCH_ALL GAME_SWITCH
 
 extern "C" int bb_game_legal(int game, int n, const void *states, uint8_t *legal_out) {
     if (n <= 0 || !states || !legal_out) return fail(BB_ERR_ARG, "bad arguments");
@@ -180,6 +176,8 @@ struct bb_engine {
     bb_config cfg;
     bb_game_info info;
     TreeDev dev;
+    DCEdges edges; // DragonChess only
+    int32_t *d_child_action = nullptr;
     NetDev net;
     bool has_weights = false;
     int net_F = 0, net_C = 0;
@@ -217,13 +215,16 @@ static int engine_alloc(bb_engine *e) {
     TreeDev &d = e->dev;
     const bb_config &c = e->cfg;
     size_t n = (size_t)c.n_slots;
-    e->node_bytes = sizeof(DenseNode<G>);
+    constexpr bool DC = G::GID == BB_GAME_DRAGONCHESS;
+    constexpr size_t NODE_BYTES = DC ? sizeof(DCNode) : sizeof(DenseNode<typename std::conditional<DC, Connect4, G>::type>);
+    constexpr size_t PSTRIDE = DC ? (size_t)G::A : (size_t)G::S;
+    e->node_bytes = NODE_BYTES;
     if (dalloc(e, d.root, n) || dalloc(e, d.root_N, n) || dalloc(e, d.n_nodes, n) || dalloc(e, d.ply, n) ||
         dalloc(e, d.sims_left, n) || dalloc(e, d.pend_leaf, n) || dalloc(e, d.pend_expand, n) ||
         dalloc(e, d.path_len, n) || dalloc(e, d.game_lid, n) || dalloc(e, d.sim_serial, n) ||
         dalloc(e, d.root_W, n) || dalloc(e, d.root_pp, n) || dalloc(e, d.path, n * G::MAXPATH) ||
         dalloc(e, d.leaf_game_id, n) || dalloc(e, d.leaf_serial, n) || dalloc(e, d.eval_value, n) ||
-        dalloc(e, d.eval_policy, n * G::S) || dalloc(e, d.ctr, n * 8) || dalloc(e, d.out_action, n) ||
+        dalloc(e, d.eval_policy, n * PSTRIDE) || dalloc(e, d.ctr, n * 8) || dalloc(e, d.out_action, n) ||
         dalloc(e, d.out_root_plays, n) || dalloc(e, d.out_child_plays, n * G::S) ||
         dalloc(e, d.out_root_winrate, n) || dalloc(e, d.out_child_value, n * G::S) || dalloc(e, e->d_u, n) ||
         dalloc(e, e->d_actions, n) || dalloc(e, d.stamps, 8))
@@ -232,8 +233,21 @@ static int engine_alloc(bb_engine *e) {
     if (dalloc(e, ls, n)) return BB_ERR_HIP;
     d.leaf_state = ls;
     uint8_t *nodes;
-    if (dalloc(e, nodes, n * (size_t)d.node_cap * sizeof(DenseNode<G>), false)) return BB_ERR_HIP;
+    if (dalloc(e, nodes, n * (size_t)d.node_cap * NODE_BYTES, false)) return BB_ERR_HIP;
     d.nodes = nodes;
+    if (dalloc(e, e->d_child_action, n * G::S)) return BB_ERR_HIP;
+    if constexpr (DC) {
+        DCEdges &E = e->edges;
+        E.edge_cap = d.node_cap * 24; // ~15-25 legal moves per position; overflow is counted, never silent
+        size_t ne = n * (size_t)E.edge_cap;
+        if (dalloc(e, E.act, ne, false) || dalloc(e, E.N, ne, false) || dalloc(e, E.Q, ne, false) ||
+            dalloc(e, E.W, ne, false) || dalloc(e, E.child, ne, false) || dalloc(e, E.cP, ne, false) ||
+            dalloc(e, E.used, n) || dalloc(e, E.path_edge, n * G::MAXPATH))
+            return BB_ERR_HIP;
+        E.noise_on = c.noise_on;
+        E.alpha = c.alpha;
+        E.eps = c.epsilon;
+    }
     size_t ng = (size_t)c.max_games;
     if (dalloc(e, d.examples, ng * (size_t)(c.max_plies + 1) * (size_t)e->info.example_bytes, false) ||
         dalloc(e, d.game_hdr, ng * 4))
@@ -445,6 +459,7 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
 template <class G> struct NetPW;
 template <> struct NetPW<Connect4> { static constexpr int v = 4; };
 template <> struct NetPW<TicTacToe> { static constexpr int v = 12; };
+template <> struct NetPW<DragonChess> { static constexpr int v = 2; };
 
 template <class G>
 static int launch_net(bb_engine *e, int n, const typename G::State *states, const int8_t *planes,
@@ -494,8 +509,12 @@ static int hash_eval(bb_engine *e, int n, const void *states, float *value, floa
     if (ds.alloc((size_t)n * sizeof(typename G::State)) || dv.alloc((size_t)n * 4) || dp.alloc((size_t)n * G::A * 4))
         return BB_ERR_HIP;
     HIPCHK(hipMemcpy(ds.p, states, (size_t)n * sizeof(typename G::State), hipMemcpyDefault));
-    k_hash_eval<G><<<nblk(n), 256, 0, e->stream>>>(n, (const typename G::State *)ds.p, nullptr, e->cfg.hash_salt, 0, 0,
-                                                   (float *)dv.p, (float *)dp.p, G::A);
+    if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+        k_dc_hash_eval<<<nblk((size_t)n * 64), 256, 0, e->stream>>>(n, (const DCState *)ds.p, nullptr, e->cfg.hash_salt, 0, 0,
+                                                                      (float *)dv.p, (float *)dp.p, G::A);
+    else
+        k_hash_eval<G><<<nblk(n), 256, 0, e->stream>>>(n, (const typename G::State *)ds.p, nullptr, e->cfg.hash_salt, 0, 0,
+                                                       (float *)dv.p, (float *)dp.p, G::A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     if (value) HIPCHK(hipMemcpy(value, dv.p, (size_t)n * 4, hipMemcpyDefault));
@@ -534,15 +553,23 @@ static int launch_eval_inner(bb_engine *e) {
     const typename G::State *ls = (const typename G::State *)d.leaf_state;
     switch (d.evaluator) {
     case BB_EVAL_HASH:
-        k_hash_eval<G><<<nblk(n), 256, 0, e->stream>>>(n, ls, d.leaf_game_id, d.salt, d.salt_per_game, d.first_game_id,
-                                                       d.eval_value, d.eval_policy, G::S);
+        if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+            k_dc_hash_eval<<<nblk((size_t)n * 64), 256, 0, e->stream>>>(n, ls, d.leaf_game_id, d.salt, d.salt_per_game,
+                                                                          d.first_game_id, d.eval_value, d.eval_policy, G::A);
+        else
+            k_hash_eval<G><<<nblk(n), 256, 0, e->stream>>>(n, ls, d.leaf_game_id, d.salt, d.salt_per_game, d.first_game_id,
+                                                           d.eval_value, d.eval_policy, G::S);
         break;
     case BB_EVAL_NET:
         return launch_net<G>(e, n, ls, nullptr, d.leaf_game_id, d.leaf_serial, e->cfg.noise_on, d.eval_value, nullptr,
-                             d.eval_policy, G::S, e->stream);
+                             d.eval_policy, (G::GID == BB_GAME_DRAGONCHESS) ? G::A : G::S, e->stream);
     case BB_EVAL_ROLLOUT:
-        k_rollout<G><<<nblk(n), 256, 0, e->stream>>>(n, ls, d.leaf_game_id, d.sim_serial, d.pend_leaf, d.seed,
-                                                     d.eval_value);
+        if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+            k_dc_rollout<<<nblk((size_t)n * 64), 256, 0, e->stream>>>(n, ls, d.leaf_game_id, d.sim_serial, d.pend_leaf, d.seed,
+                                                                        d.eval_value);
+        else
+            k_rollout<G><<<nblk(n), 256, 0, e->stream>>>(n, ls, d.leaf_game_id, d.sim_serial, d.pend_leaf, d.seed,
+                                                         d.eval_value);
         break;
     default: return fail(BB_ERR_ARG, "unknown evaluator %d", d.evaluator);
     }
@@ -555,7 +582,10 @@ static int run_sims(bb_engine *e, int sims) {
     TreeDev &d = e->dev;
     int tb = nblk((size_t)((d.n_slots + d.gpw - 1) / d.gpw) * 64);
     for (int s = 0; s < sims; s++) {
-        k_tree_step<G><<<tb, 256, 0, e->stream>>>(d);
+        if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+            k_dc_tree_step<<<nblk((size_t)d.n_slots * 64), 256, 0, e->stream>>>(d, e->edges);
+        else
+            k_tree_step<G><<<tb, 256, 0, e->stream>>>(d);
         HIPCHK(hipGetLastError());
         int rc = launch_eval<G>(e);
         if (rc) return rc;
@@ -577,8 +607,12 @@ static int set_roots(bb_engine *e, int n, const int32_t *slots, const void *stat
     HIPCHK(hipMemcpy(ds.p, states, (size_t)n * sizeof(typename G::State), hipMemcpyDefault));
     if (slots) HIPCHK(hipMemcpy(dsl.p, slots, (size_t)n * 4, hipMemcpyDefault));
     if (gids) HIPCHK(hipMemcpy(dg.p, gids, (size_t)n * 4, hipMemcpyDefault));
-    k_set_roots<G><<<nblk(n), 256, 0, e->stream>>>(e->dev, n, slots ? (const int32_t *)dsl.p : nullptr,
-                                                   (const typename G::State *)ds.p, gids ? (const uint32_t *)dg.p : nullptr);
+    if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+        k_dc_set_roots<<<nblk(n), 256, 0, e->stream>>>(e->dev, e->edges, n, slots ? (const int32_t *)dsl.p : nullptr,
+                                                         (const DCState *)ds.p, gids ? (const uint32_t *)dg.p : nullptr);
+    else
+        k_set_roots<G><<<nblk(n), 256, 0, e->stream>>>(e->dev, n, slots ? (const int32_t *)dsl.p : nullptr,
+                                                       (const typename G::State *)ds.p, gids ? (const uint32_t *)dg.p : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     return BB_OK;
@@ -596,10 +630,13 @@ extern "C" int bb_run_sims(bb_engine *e, int sims) {
     if (rc) return rc;
     HIPCHK(hipSetDevice(e->cfg.device));
     GAME_SWITCH(e->cfg.game, {
-        k_add_sims<G><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, sims);
+        k_add_sims<typename std::conditional<G::GID == BB_GAME_DRAGONCHESS, Connect4, G>::type><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, sims);
         rc = run_sims<G>(e, sims);
         if (rc) return rc;
-        k_tree_apply<G><<<nblk((size_t)e->dev.n_slots * G::S), 256, 0, e->stream>>>(e->dev);
+        if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+            k_dc_tree_apply<<<nblk((size_t)e->dev.n_slots * 64), 256, 0, e->stream>>>(e->dev, e->edges);
+        else
+            k_tree_apply<G><<<nblk((size_t)e->dev.n_slots * G::S), 256, 0, e->stream>>>(e->dev);
         HIPCHK(hipGetLastError());
         return BB_OK;
     });
@@ -616,7 +653,10 @@ static int sample_moves(bb_engine *e, double temp, const double *u, int32_t *act
     } else {
         d.in_u = nullptr;
     }
-    k_sample<G><<<nblk(n * G::S), 256, 0, e->stream>>>(d, temp);
+    if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+        k_dc_sample<<<nblk(n * 64), 256, 0, e->stream>>>(d, e->edges, temp, e->d_child_action);
+    else
+        k_sample<G><<<nblk(n * G::S), 256, 0, e->stream>>>(d, temp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     if (action) HIPCHK(hipMemcpy(action, d.out_action, n * 4, hipMemcpyDefault));
@@ -624,7 +664,9 @@ static int sample_moves(bb_engine *e, double temp, const double *u, int32_t *act
     if (rp) HIPCHK(hipMemcpy(rp, d.out_root_plays, n * 4, hipMemcpyDefault));
     if (cplays) HIPCHK(hipMemcpy(cplays, d.out_child_plays, n * G::S * 4, hipMemcpyDefault));
     if (cval) HIPCHK(hipMemcpy(cval, d.out_child_value, n * G::S * 4, hipMemcpyDefault));
-    if (cact) { // dense games: slot i is action i
+    if constexpr (G::GID == BB_GAME_DRAGONCHESS) {
+        if (cact) HIPCHK(hipMemcpy(cact, e->d_child_action, n * G::S * 4, hipMemcpyDefault));
+    } else if (cact) { // dense games: slot i is action i
         std::vector<int32_t> ca(n * G::S);
         for (size_t g = 0; g < n; g++)
             for (int i = 0; i < G::S; i++) ca[g * G::S + i] = i < G::A ? i : -1;
@@ -647,7 +689,10 @@ extern "C" int bb_move_roots(bb_engine *e, const int32_t *actions) {
     HIPCHK(hipSetDevice(e->cfg.device));
     HIPCHK(hipMemcpyAsync(e->d_actions, actions, (size_t)e->dev.n_slots * 4, hipMemcpyDefault, e->stream));
     GAME_SWITCH(e->cfg.game, {
-        k_move_roots<G><<<nblk((size_t)e->dev.n_slots * G::S), 256, 0, e->stream>>>(e->dev, e->d_actions);
+        if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+            k_dc_move_roots<<<nblk((size_t)e->dev.n_slots * 64), 256, 0, e->stream>>>(e->dev, e->edges, e->d_actions);
+        else
+            k_move_roots<G><<<nblk((size_t)e->dev.n_slots * G::S), 256, 0, e->stream>>>(e->dev, e->d_actions);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(e->stream));
         return BB_OK;
@@ -661,7 +706,10 @@ extern "C" int bb_get_root_states(bb_engine *e, void *states_out) {
         DevBuf ds;
         size_t bytes = (size_t)e->dev.n_slots * sizeof(typename G::State);
         if (ds.alloc(bytes)) return BB_ERR_HIP;
-        k_get_roots<G><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, (typename G::State *)ds.p);
+        if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+            k_dc_get_roots<<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, (DCState *)ds.p);
+        else
+            k_get_roots<G><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, (typename G::State *)ds.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(e->stream));
         HIPCHK(hipMemcpy(states_out, ds.p, bytes, hipMemcpyDefault));
@@ -678,7 +726,7 @@ extern "C" int bb_set_sims_per_move(bb_engine *e, int sims) {
     e->sims_now = sims;
     e->dev.sims_per_move = sims;
     GAME_SWITCH(e->cfg.game, {
-        k_add_sims<G><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, sims); // slots waiting for their next move
+        k_add_sims<typename std::conditional<G::GID == BB_GAME_DRAGONCHESS, Connect4, G>::type><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, sims); // slots waiting for their next move
         HIPCHK(hipGetLastError());
         return BB_OK;
     });
@@ -700,7 +748,10 @@ extern "C" int bb_selfplay_begin(bb_engine *e, int n_games, double temp) {
     e->dev.temp = temp;
     HIPCHK(hipMemsetAsync(e->dev.game_hdr, 0, (size_t)e->cfg.max_games * 16, e->stream));
     GAME_SWITCH(e->cfg.game, {
-        k_selfplay_begin<G><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev);
+        if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+            k_dc_selfplay_begin<<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, e->edges);
+        else
+            k_selfplay_begin<G><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev);
         HIPCHK(hipGetLastError());
         return BB_OK;
     });
@@ -714,7 +765,10 @@ extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
         for (int p = 0; p < plies; p++) {
             int rc = run_sims<G>(e, e->sims_now);
             if (rc) return rc;
-            k_selfplay_move<G><<<nblk((size_t)e->dev.n_slots * G::S), 256, 0, e->stream>>>(e->dev);
+            if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+                k_dc_selfplay_move<<<nblk((size_t)e->dev.n_slots * 64), 256, 0, e->stream>>>(e->dev, e->edges);
+            else
+                k_selfplay_move<G><<<nblk((size_t)e->dev.n_slots * G::S), 256, 0, e->stream>>>(e->dev);
             HIPCHK(hipGetLastError());
         }
         return BB_OK;

@@ -86,11 +86,10 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
 #pragma unroll
             for (int c = 0; c < CIN; c++) dst[c] = (float)src[c];
         } else {
-            int8_t v[3];
+            int8_t v[CIN];
             G::encode_cell(states[pos], y, x, v);
-            dst[0] = (float)v[0];
-            dst[1] = (float)v[1];
-            dst[2] = (float)v[2];
+#pragma unroll
+            for (int c = 0; c < CIN; c++) dst[c] = (float)v[c];
         }
     }
     // ---- per-tile addressing: lane (j, nn) <-> pixel nn of the tile, channels 4j..4j+3 ---------
@@ -217,15 +216,58 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
             for (int p = 0; p < HW; p++) s += __builtin_fmaf(rv[pp * HW + p], wk, wb);
             sd[q] = fmaxf(s, 0.f);
         }
-        const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
-        for (int q = lane; q < PW * A; q += 64) { // policy dense on the last axis, reduce_sum over H,W
-            int pp = q / A, a = q % A;
-            float s = 0.f, k0 = pdk[a], k1 = pdk[A + a], kb = pdb[a];
-            for (int p = 0; p < HW; p++)
-                s += __builtin_fmaf(rp[2 * (pp * HW + p) + 1], k1, __builtin_fmaf(rp[2 * (pp * HW + p)], k0, kb));
-            lg[q] = s;
+        if constexpr (A <= 64) {
+            const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
+            for (int q = lane; q < PW * A; q += 64) { // policy dense on the last axis, reduce_sum over H,W
+                int pp = q / A, a = q % A;
+                float s = 0.f, k0 = pdk[a], k1 = pdk[A + a], kb = pdb[a];
+                for (int p = 0; p < HW; p++)
+                    s += __builtin_fmaf(rp[2 * (pp * HW + p) + 1], k1, __builtin_fmaf(rp[2 * (pp * HW + p)], k0, kb));
+                lg[q] = s;
+            }
         }
     }
+    if constexpr (A > 64) {
+        // wide policy (DragonChess, A = 4032): logits[a] = sum_p (r1[p]*k1[a] + (r0[p]*k0[a] + b[a])) in the
+        // oracle's pixel order, lanes stride the actions; softmax max/sum are wave reductions.
+        const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
+        const int D = nd.D;
+        const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
+        for (int pp = 0; pp < PW; pp++) {
+            int pos = pos0 + pp;
+            if (pos >= n) break;
+            float *outp = policy_out ? policy_out + (size_t)pos * pstride : nullptr;
+            float m = -INFINITY;
+            for (int a = lane; a < A; a += 64) {
+                float s = 0.f, k0 = pdk[a], k1 = pdk[A + a], kb = pdb[a];
+                for (int p = 0; p < HW; p++)
+                    s += __builtin_fmaf(rp[2 * (pp * HW + p) + 1], k1, __builtin_fmaf(rp[2 * (pp * HW + p)], k0, kb));
+                if (logits_out) logits_out[(size_t)pos * A + a] = s;
+                if (outp) outp[a] = s;
+                m = fmaxf(m, s);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            float tot = 0.f;
+            if (outp) {
+                for (int a = lane; a < A; a += 64) {
+                    float e = expf(outp[a] - m);
+                    outp[a] = e;
+                    tot += e;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+                for (int a = lane; a < A; a += 64) outp[a] = outp[a] / tot;
+            }
+            if (lane == 0 && value_out) {
+                float e = d2b[0];
+                for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(sd[pp * D + dd], d2k[dd], e);
+                value_out[pos] = tanhf(e);
+            }
+        }
+        return; // prior noise for wide games is mixed in at expansion (tree_dc.hip.h)
+    }
+    if constexpr (A <= 64) {
     float *nz = lg + PW * A; // [PW][A] Beta(alpha, 1-alpha) draws, one lane per (position, action)
     if (noise)
         for (int q = lane; q < PW * A; q += 64) {
@@ -266,5 +308,6 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
         if (policy_out)
 #pragma unroll
             for (int a = 0; a < A; a++) policy_out[(size_t)pos * pstride + a] = pr[a];
+    }
     }
 }

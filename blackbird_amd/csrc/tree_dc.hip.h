@@ -1,0 +1,657 @@
+// tree_dc.hip.h -- node-pool MCTS for DragonChess (wide action space, compact child lists).
+//
+// A=4032 but a position has <= 137 legal moves, so a node owns a contiguous run of "edges"
+// (action id, N, Q, W, child, c_puct*prior) in its slot's edge pool instead of a dense row.  One
+// 64-lane wave serves one game: lane = from-square during move generation, lane = edge index (mod 64)
+// during selection.  Semantics are those of tree.hip.h (same reference lines); what differs:
+//   * priors: np.sum over the dense 4032-vector is numpy's pairwise tree (32 blocks of 126 with 8
+//     partial sums each); reproduced over an LDS image of the dense vector so illegal zeros sit
+//     where numpy sees them;
+//   * prior noise is drawn for the legal moves only, at expansion: the reference's normalisation
+//     over all 4032 actions (NetworkFactory.py:182) cancels in GetPriors' renormalisation
+//     (Blackbird.py:386-387), so the distribution of the priors is the same.
+#pragma once
+#include "tree.hip.h"
+
+struct alignas(128) DCNode {
+    int32_t flags;    // NODE_EXPANDED | NODE_TERMINAL | Player << 4 | (winner+1) << 8
+    int32_t n_edges;  // sum(LegalActions)
+    int32_t edge_off; // first edge in the slot's edge pool
+    int32_t all;      // sum(ChildPlays)
+    double sq;        // sqrt(1.0 + all)
+    int32_t serial, pad;
+    DCState st;
+};
+static_assert(sizeof(DCNode) == 128, "DragonChess node row is one 128-byte line");
+
+struct DCEdges { // per-slot SoA edge pool, stride edge_cap
+    uint16_t *act;
+    int32_t *N;
+    float *Q, *W;
+    int32_t *child;
+    double *cP;
+    int32_t *used; // [n_slots] allocation cursor
+    uint32_t *path_edge; // [n_slots][MAXPATH] absolute edge index | player << 30
+    int edge_cap;
+    int noise_on;
+    float alpha, eps;
+};
+
+// ---- wave (64 lanes) collectives ----------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_excl_scan_i(int v, int lane) {
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    return x - v;
+}
+// first maximum (lowest idx on ties); idx < 0 marks "no candidate"
+__device__ __forceinline__ void wave_argmax(double &u, int &idx, int &p0, int &p1) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        double ou = __shfl_xor(u, o, 64);
+        int oi = __shfl_xor(idx, o, 64), q0 = __shfl_xor(p0, o, 64), q1 = __shfl_xor(p1, o, 64);
+        bool take = oi >= 0 && (idx < 0 || ou > u || (ou == u && oi < idx));
+        if (take) {
+            u = ou;
+            idx = oi;
+            p0 = q0;
+            p1 = q1;
+        }
+    }
+}
+
+// numpy pairwise add.reduce over the dense float64 image a[4032] in LDS.  numpy's recursion
+// (n > 128: n2 = n/2 rounded down to a multiple of 8; pairwise(a, n2) + pairwise(a+n2, n-n2)) cuts 4032
+// into 16 runs of 252 = leaf(120) + (leaf(64) + leaf(68)); a leaf keeps 8 strided partials, folds them
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and adds its tail sequentially.  Lane 3*run+part sums one leaf.
+__device__ __forceinline__ double dc_np_sum(const double *a, int lane) {
+    double res = 0.0;
+    if (lane < 48) {
+        int run = lane / 3, part = lane % 3;
+        int off = run * 252 + (part == 0 ? 0 : part == 1 ? 120 : 184);
+        int len = part == 0 ? 120 : part == 1 ? 64 : 68;
+        const double *b = a + off;
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = b[j];
+        int i = 8;
+        for (; i < len - (len % 8); i += 8)
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] += b[i + j];
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < len; i++) res += b[i];
+    }
+    double nxt = __shfl_down(res, 1, 64);
+    double r12 = res + nxt;                      // meaningful on part-1 lanes: leaf(64) + leaf(68)
+    double nxt12 = __shfl_down(r12, 1, 64);
+    double run_sum = res + nxt12;                // meaningful on part-0 lanes: leaf(120) + (...)
+    double v = __shfl(run_sum, (3 * lane) & 63, 64); // lanes 0..15 <- runs 0..15
+    if (lane >= 16) v = 0.0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        double right = __shfl_down(v, o, 64);
+        if ((lane & (2 * o - 1)) == 0) v = v + right;
+    }
+    return __shfl(v, 0, 64);
+}
+
+// AddChildren for the node `node` (state st): move generation (lane = from-square), priors, edge rows.
+// policy == nullptr -> MCTS.GetPriors default (ones).  lds: 4032 doubles of scratch owned by this wave.
+__device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *node, const DCState &st,
+                          const float *policy, uint32_t gid, int lane, double *lds) {
+    uint64_t m = DragonChess::targets(st, lane);
+    int cnt = bb_popc64(m);
+    int pre = wave_excl_scan_i(cnt, lane);
+    int total = wave_sum_i(cnt);
+    int off = E.used[g];
+    if (off + total > E.edge_cap) return false;
+    double tot = 1.0;
+    if (policy) {
+        for (int i = lane; i < 4032; i += 64) lds[i] = 0.0;
+        uint64_t mm = m;
+        while (mm) {
+            int sq2 = bb_ctz64(mm);
+            mm &= mm - 1;
+            int a = DragonChess::action_id(lane, sq2);
+            float p = policy[a];
+            if (E.noise_on) p = (1.0f - E.eps) * p + E.eps * bb_beta_noise(d.seed, gid, (uint32_t)node->serial, (uint32_t)a, E.alpha);
+            lds[a] = (double)p; // float32 * float64 legal mask (1.0)
+        }
+        tot = dc_np_sum(lds, lane);
+    }
+    size_t base = (size_t)g * E.edge_cap + off;
+    uint64_t mm = m;
+    int k = pre;
+    while (mm) {
+        int sq2 = bb_ctz64(mm);
+        mm &= mm - 1;
+        int a = DragonChess::action_id(lane, sq2);
+        size_t e = base + k++;
+        E.act[e] = (uint16_t)a;
+        E.N[e] = 0;
+        E.Q[e] = 0.f;
+        E.W[e] = 0.f;
+        E.child[e] = CHILD_NONE;
+        E.cP[e] = policy ? d.c_puct * __ddiv_rn(lds[a], tot) : d.c_puct * 1.0;
+    }
+    if (lane == 0) {
+        node->flags |= NODE_EXPANDED;
+        node->n_edges = total;
+        node->edge_off = off;
+        node->all = 0;
+        node->sq = 1.0;
+        E.used[g] = off + total;
+    }
+    return true;
+}
+
+__device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int lane, double *lds) {
+    int leaf = d.pend_leaf[g];
+    if (leaf < 0) return;
+    DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
+    DCNode *node = pool + leaf;
+    DCState st = ((const DCState *)d.leaf_state)[g];
+    float v = d.eval_value[g];
+    if (d.pend_expand[g]) {
+        uint32_t gid = d.first_game_id + (uint32_t)d.game_lid[g];
+        if (!dc_expand(d, E, g, node, st, d.eval_policy + (size_t)g * 4032, gid, lane, lds) && lane == 0)
+            d.ctr[(size_t)g * 8 + 6] += 1;
+    }
+    int player = st.player, prev = st.prev;
+    float v01;
+    if (d.evaluator == 2) {
+        v01 = v;
+    } else {
+        v01 = (v + 1.0f) * 0.5f;
+        if (player != prev) v01 = 1.0f - v01;
+    }
+    float vflip = 1.0f - v01;
+    int plen = d.path_len[g];
+    const uint32_t *pn = d.path + (size_t)g * DragonChess::MAXPATH;
+    const uint32_t *pe = E.path_edge + (size_t)g * DragonChess::MAXPATH;
+    for (int k = lane; k < plen; k += 64) {
+        DCNode *nd = pool + pn[k];
+        uint32_t ew = pe[k];
+        int pl = (int)(ew >> 30);
+        size_t e = (size_t)g * E.edge_cap + (ew & 0x3FFFFFFFu);
+        int n = E.N[e] + 1, all = nd->all + 1;
+        float w = E.W[e] + ((pl == prev) ? v01 : vflip);
+        E.N[e] = n;
+        E.W[e] = w;
+        E.Q[e] = __fdiv_rn(w, (float)n);
+        nd->all = all;
+        nd->sq = __dsqrt_rn(1.0 + (double)all);
+    }
+    if (lane == 0) {
+        d.root_N[g] += 1;
+        int pp = d.root_pp[g];
+        if (pp) d.root_W[g] += (pp == prev) ? v01 : vflip;
+        d.pend_leaf[g] = -1;
+    }
+}
+
+// create the child reached by edge e (absolute) of parent; lane 0 writes
+__device__ __forceinline__ int dc_create_child(const TreeDev &d, const DCEdges &E, int g, DCNode *pool, const DCState &pst,
+                                               int action, size_t e, int lane, int &nn, DCState &st2, bool &terminal) {
+    int idx = nn;
+    st2 = pst;
+    DragonChess::apply(st2, action);
+    int w = DragonChess::winner(st2, action);
+    terminal = w >= 0;
+    if (idx >= d.node_cap) return CHILD_NONE;
+    int word = idx | (terminal ? CHILD_TERM_BIT : 0);
+    nn = idx + 1;
+    if (lane == 0) {
+        DCNode *c = pool + idx;
+        c->st = st2;
+        c->flags = (terminal ? (NODE_TERMINAL | ((w + 1) << 8)) : 0) | ((int)st2.player << 4);
+        c->n_edges = 0;
+        c->edge_off = 0;
+        c->all = 0;
+        c->serial = idx;
+        E.child[e] = word;
+        d.n_nodes[g] = idx + 1;
+        d.ctr[(size_t)g * 8 + 2] += 1;
+    }
+    return word;
+}
+
+__device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int lane, double *lds) {
+    if (d.game_lid[g] < 0 || d.sims_left[g] <= 0) return;
+    DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
+    uint32_t *pn = d.path + (size_t)g * DragonChess::MAXPATH;
+    uint32_t *pe = E.path_edge + (size_t)g * DragonChess::MAXPATH;
+    int cur = d.root[g];
+    int nn = d.n_nodes[g];
+    int depth = 0, expand = 0, overflow = 0, term_leaf = 0;
+    const bool inline_expand = d.priors_ones != 0;
+    const bool fixed = d.kind == 1, rollout = d.evaluator == 2;
+    DCState st;
+    int flags = 0;
+    bool have = false;
+    for (int it = 0;; it++) {
+        DCNode *node = pool + cur;
+        if (!have) {
+            flags = node->flags;
+        }
+        int n_edges = node->n_edges, edge_off = node->edge_off;
+        double sq = node->sq;
+        bool have_st = have;
+        have = false;
+        if (fixed && it >= d.max_depth) {
+            if (!have_st) st = node->st;
+            break;
+        }
+        if (!(flags & NODE_EXPANDED)) {
+            if (!have_st) st = node->st;
+            if (flags & NODE_TERMINAL) { term_leaf = 1; break; }
+            if (!inline_expand) { expand = 1; break; }
+            if (!dc_expand(d, E, g, node, st, nullptr, 0u, lane, lds)) { overflow = 1; break; }
+            __threadfence_block();
+            if (!fixed) break;
+            n_edges = node->n_edges;
+            edge_off = node->edge_off;
+            sq = 1.0;
+        }
+        if (n_edges == 0) {
+            if (!have_st) st = node->st;
+            break;
+        }
+        // PUCT over the node's edges, 64 per pass
+        double bu = -1.0;
+        int bi = -1, bchild = CHILD_NONE, bact = 0;
+        size_t base = (size_t)g * E.edge_cap + edge_off;
+        for (int k = lane; k < n_edges; k += 64) {
+            size_t e = base + k;
+            int Ni = E.N[e];
+            double q = child_q(d, E.Q[e], rollout ? E.W[e] : 0.f, Ni);
+            double u = puct_score(q, E.cP[e], sq, Ni, true);
+            if (bi < 0 || u > bu) {
+                bu = u;
+                bi = k;
+                bchild = E.child[e];
+                bact = E.act[e];
+            }
+        }
+        wave_argmax(bu, bi, bchild, bact);
+        if (depth >= DragonChess::MAXPATH) { overflow = 1; if (!have_st) st = node->st; break; }
+        int child = bchild;
+        if (lane == 0) {
+            pn[depth] = (uint32_t)cur;
+            pe[depth] = (uint32_t)(edge_off + bi) | ((uint32_t)((flags >> 4) & 3) << 30);
+        }
+        if (child == CHILD_NONE) {
+            DCState pst = node->st, st2;
+            bool terminal;
+            child = dc_create_child(d, E, g, pool, pst, bact, base + bi, lane, nn, st2, terminal);
+            if (child == CHILD_NONE) { overflow = 1; st = pst; break; }
+            st = st2;
+            flags = (terminal ? NODE_TERMINAL : 0) | ((int)st2.player << 4);
+            have = true;
+            __threadfence_block();
+        }
+        depth++;
+        cur = child & ~CHILD_TERM_BIT;
+    }
+    if (lane == 0) {
+        ((DCState *)d.leaf_state)[g] = st;
+        d.leaf_game_id[g] = d.first_game_id + (uint32_t)d.game_lid[g];
+        d.leaf_serial[g] = cur;
+        d.pend_leaf[g] = cur;
+        d.pend_expand[g] = expand;
+        d.path_len[g] = depth;
+        d.sims_left[g] -= 1;
+        d.sim_serial[g] += 1;
+        uint64_t *c = d.ctr + (size_t)g * 8;
+        c[0] += 1;
+        c[1] += (uint64_t)depth;
+        c[3] += (uint64_t)term_leaf;
+        c[6] += (uint64_t)overflow;
+    }
+}
+
+#define DC_LDS_DOUBLES 4032
+__global__ void __launch_bounds__(256) k_dc_tree_step(TreeDev d, DCEdges E) {
+    __shared__ double lds[4][DC_LDS_DOUBLES];
+    int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (g >= d.n_slots) return;
+    dc_phase_apply(d, E, g, lane, lds[wv]);
+    __threadfence_block();
+    dc_phase_select(d, E, g, lane, lds[wv]);
+}
+
+__global__ void __launch_bounds__(256) k_dc_tree_apply(TreeDev d, DCEdges E) {
+    __shared__ double lds[4][DC_LDS_DOUBLES];
+    int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (g >= d.n_slots) return;
+    dc_phase_apply(d, E, g, lane, lds[wv]);
+}
+
+// ---- root statistics / move choice ------------------------------------------------------------------------
+// lane 0 walks the (<=144) edges: the np.random.choice law needs the sequential cumsum
+__device__ int dc_choose_move(const TreeDev &d, const DCEdges &E, int g, int lane, double temp, double u, int &total,
+                              int &edge_out) {
+    DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
+    DCNode *node = pool + d.root[g];
+    int act = -3, tot = 0, eo = -1;
+    if (lane == 0 && (node->flags & NODE_EXPANDED)) {
+        int n = node->n_edges;
+        size_t base = (size_t)g * E.edge_cap + node->edge_off;
+        for (int k = 0; k < n; k++) tot += E.N[base + k];
+        if (temp == 0.0) {
+            double bu = -1.0;
+            for (int k = 0; k < n; k++) {
+                int Ni = E.N[base + k];
+                double uu = puct_score(child_q(d, E.Q[base + k], E.W[base + k], Ni), E.cP[base + k], node->sq, Ni, true);
+                if (eo < 0 || uu > bu) {
+                    bu = uu;
+                    eo = k;
+                }
+            }
+            act = n > 0 ? (int)E.act[base + eo] : -4;
+        } else {
+            double it = 1.0 / temp, allp = 0.0;
+            for (int k = 0; k < n; k++) {
+                double c = (double)E.N[base + k];
+                allp += (it == 1.0) ? c : pow(c, it);
+            }
+            if (!(allp > 0.0)) {
+                act = -4;
+            } else {
+                double last = 0.0;
+                for (int k = 0; k < n; k++) {
+                    double c = (double)E.N[base + k];
+                    last += __ddiv_rn((it == 1.0) ? c : pow(c, it), allp);
+                }
+                double run = 0.0;
+                eo = n - 1;
+                for (int k = 0; k < n; k++) {
+                    double c = (double)E.N[base + k];
+                    run += __ddiv_rn((it == 1.0) ? c : pow(c, it), allp);
+                    if (__ddiv_rn(run, last) > u) {
+                        eo = k;
+                        break;
+                    }
+                }
+                act = (int)E.act[base + eo];
+            }
+        }
+    }
+    total = __shfl(tot, 0, 64);
+    edge_out = __shfl(eo, 0, 64);
+    return __shfl(act, 0, 64);
+}
+
+__global__ void __launch_bounds__(256) k_dc_sample(TreeDev d, DCEdges E, double temp, int32_t *out_child_action) {
+    int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (g >= d.n_slots) return;
+    constexpr int S = DragonChess::S;
+    for (int k = lane; k < S; k += 64) {
+        if (d.out_child_plays) d.out_child_plays[(size_t)g * S + k] = 0;
+        if (d.out_child_value) d.out_child_value[(size_t)g * S + k] = 0.f;
+        if (out_child_action) out_child_action[(size_t)g * S + k] = -1;
+    }
+    if (d.game_lid[g] < 0) {
+        if (lane == 0 && d.out_action) d.out_action[g] = -3;
+        return;
+    }
+    double u = d.in_u ? d.in_u[g] : bb_u53(d.seed, d.first_game_id + (uint32_t)d.game_lid[g], (uint32_t)d.ply[g]);
+    int total, eo;
+    int act = dc_choose_move(d, E, g, lane, temp, u, total, eo);
+    DCNode *node = (DCNode *)d.nodes + (size_t)g * d.node_cap + d.root[g];
+    if (node->flags & NODE_EXPANDED) {
+        size_t base = (size_t)g * E.edge_cap + node->edge_off;
+        for (int k = lane; k < node->n_edges; k += 64) {
+            if (d.out_child_plays) d.out_child_plays[(size_t)g * S + k] = E.N[base + k];
+            if (d.out_child_value) d.out_child_value[(size_t)g * S + k] = E.W[base + k];
+            if (out_child_action) out_child_action[(size_t)g * S + k] = E.act[base + k];
+        }
+    }
+    if (lane == 0) {
+        if (d.out_action) d.out_action[g] = act;
+        if (d.out_root_plays) d.out_root_plays[g] = d.root_N[g];
+        if (d.out_root_winrate) {
+            int n = d.root_N[g];
+            float w = d.root_W[g];
+            d.out_root_winrate[g] = n > 0 ? ((d.evaluator == 2) ? (float)((double)w / (double)n) : __fdiv_rn(w, (float)n)) : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void dc_reset_slot(const TreeDev &d, const DCEdges &E, int g, int lid, const DCState &st) {
+    DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
+    pool->st = st;
+    pool->flags = (int)st.player << 4;
+    pool->n_edges = 0;
+    pool->edge_off = 0;
+    pool->all = 0;
+    pool->serial = 0;
+    d.n_nodes[g] = 1;
+    E.used[g] = 0;
+    d.root[g] = 0;
+    d.root_N[g] = 0;
+    d.root_W[g] = 0.f;
+    d.root_pp[g] = 0;
+    d.ply[g] = 0;
+    d.pend_leaf[g] = -1;
+    d.pend_expand[g] = 0;
+    d.path_len[g] = 0;
+    d.sim_serial[g] = 0;
+    d.game_lid[g] = lid;
+}
+
+// _moveRoot by action id (all lanes call; lane 0 writes)
+__device__ void dc_advance_root(const TreeDev &d, const DCEdges &E, int g, int lane, int action, DCState &new_st) {
+    DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
+    DCNode *node = pool + d.root[g];
+    DCState st = node->st;
+    if (!(node->flags & NODE_EXPANDED)) {
+        new_st = st;
+        DragonChess::apply(new_st, action);
+        if (lane == 0) dc_reset_slot(d, E, g, d.game_lid[g], new_st);
+        return;
+    }
+    int n = node->n_edges;
+    size_t base = (size_t)g * E.edge_cap + node->edge_off;
+    int k = -1;
+    for (int i = lane; i < n; i += 64)
+        if ((int)E.act[base + i] == action) k = i;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) k = max(k, __shfl_xor(k, o, 64));
+    if (k < 0) { // not a legal move of the root: leave the tree alone (the next FindMove asserts)
+        new_st = st;
+        return;
+    }
+    size_t e = base + k;
+    int child = E.child[e], cn = E.N[e];
+    float cw = E.W[e];
+    if (child == CHILD_NONE) {
+        bool terminal;
+        int nn = d.n_nodes[g];
+        child = dc_create_child(d, E, g, pool, st, action, e, lane, nn, new_st, terminal);
+        if (child == CHILD_NONE) {
+            if (lane == 0) {
+                int lid = d.game_lid[g], ply = d.ply[g];
+                dc_reset_slot(d, E, g, lid, new_st);
+                d.ply[g] = ply;
+                d.ctr[(size_t)g * 8 + 6] += 1;
+            }
+            return;
+        }
+    } else {
+        new_st = pool[child & ~CHILD_TERM_BIT].st;
+    }
+    if (lane == 0) {
+        d.root[g] = child & ~CHILD_TERM_BIT;
+        d.root_N[g] = cn;
+        d.root_W[g] = cw;
+        d.root_pp[g] = st.player;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_dc_move_roots(TreeDev d, DCEdges E, const int32_t *actions) {
+    int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (g >= d.n_slots) return;
+    int a = actions[g];
+    if (a < 0 || a >= DragonChess::A || d.game_lid[g] < 0) return;
+    DCState ns;
+    dc_advance_root(d, E, g, lane, a, ns);
+    if (lane == 0) d.ply[g] += 1;
+}
+
+__global__ void __launch_bounds__(256) k_dc_set_roots(TreeDev d, DCEdges E, int n, const int32_t *slots, const DCState *states,
+                                                      const uint32_t *game_ids) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int g = slots ? slots[i] : i;
+    if (g < 0 || g >= d.n_slots) return;
+    dc_reset_slot(d, E, g, game_ids ? (int)game_ids[i] : g, states[i]);
+    d.sims_left[g] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_dc_get_roots(TreeDev d, DCState *out) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.n_slots) return;
+    out[g] = ((DCNode *)d.nodes + (size_t)g * d.node_cap + d.root[g])->st;
+}
+
+__global__ void __launch_bounds__(256) k_dc_selfplay_begin(TreeDev d, DCEdges E) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.n_slots) return;
+    if (g < d.n_games_target) {
+        dc_reset_slot(d, E, g, g, DragonChess::initial());
+        d.sims_left[g] = d.sims_per_move;
+    } else {
+        dc_reset_slot(d, E, g, -1, DragonChess::initial());
+        d.sims_left[g] = 0;
+    }
+}
+
+// example record: ExampleHdr, DCState, u32 visits[S], u16 action[S]
+__device__ void dc_write_example(const TreeDev &d, const DCEdges &E, int lid, int ply, const DCNode *node, const DCState &st,
+                                 int g, int lane, int total, uint32_t gid, bool terminal_example) {
+    constexpr int S = DragonChess::S;
+    uint8_t *p = d.examples + ((size_t)lid * (d.max_plies + 1) + ply) * d.example_bytes;
+    uint32_t *vis = (uint32_t *)(p + sizeof(ExampleHdr) + sizeof(DCState));
+    uint16_t *act = (uint16_t *)(p + sizeof(ExampleHdr) + sizeof(DCState) + 4 * S);
+    int n = terminal_example ? 0 : node->n_edges;
+    size_t base = terminal_example ? 0 : (size_t)g * E.edge_cap + node->edge_off;
+    for (int k = lane; k < S; k += 64) {
+        vis[k] = k < n ? (uint32_t)E.N[base + k] : 0u;
+        act[k] = k < n ? E.act[base + k] : (uint16_t)0xFFFF;
+    }
+    if (lane == 0) {
+        ExampleHdr h;
+        h.game_id = gid;
+        h.ply = (uint16_t)ply;
+        h.player = (uint8_t)st.player;
+        h.z = 0;
+        h.total = (uint32_t)total;
+        h.n_children = (uint32_t)n;
+        *(ExampleHdr *)p = h;
+        *(DCState *)(p + sizeof(ExampleHdr)) = st;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_dc_selfplay_move(TreeDev d, DCEdges E) {
+    __shared__ double lds[4][DC_LDS_DOUBLES];
+    int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (g >= d.n_slots) return;
+    dc_phase_apply(d, E, g, lane, lds[wv]);
+    __threadfence_block();
+    int lid = d.game_lid[g];
+    if (lid < 0) return;
+    DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
+    DCNode *root = pool + d.root[g];
+    DCState st = root->st;
+    uint32_t gid = d.first_game_id + (uint32_t)lid;
+    int ply = d.ply[g];
+    double u = bb_u53(d.seed, gid, (uint32_t)ply);
+    int total, eo;
+    int act = dc_choose_move(d, E, g, lane, d.temp, u, total, eo);
+    if (act < 0) {
+        if (lane == 0) {
+            d.game_lid[g] = -1;
+            d.ctr[(size_t)g * 8 + 6] += 1;
+        }
+        return;
+    }
+    dc_write_example(d, E, lid, ply, root, st, g, lane, total, gid, false);
+    DCState ns;
+    dc_advance_root(d, E, g, lane, act, ns);
+    __threadfence_block();
+    ply += 1;
+    int w = DragonChess::winner(ns, -1);
+    bool over = w >= 0 || ply >= d.max_plies;
+    if (!over) {
+        if (lane == 0) {
+            d.ply[g] = ply;
+            d.sims_left[g] = d.sims_per_move;
+            d.ctr[(size_t)g * 8 + 5] += 1;
+        }
+        return;
+    }
+    dc_write_example(d, E, lid, ply, nullptr, ns, g, lane, 0, gid, true);
+    __threadfence_block();
+    for (int k = lane; k <= ply; k += 64) {
+        ExampleHdr *h = (ExampleHdr *)(d.examples + ((size_t)lid * (d.max_plies + 1) + k) * d.example_bytes);
+        h->z = (w <= 0) ? 0 : (h->player == w ? 1 : -1);
+    }
+    if (lane == 0) {
+        int32_t *gh = d.game_hdr + (size_t)lid * 4;
+        gh[0] = ply + 1;
+        gh[1] = w;
+        gh[2] = ply;
+        gh[3] = 1;
+        uint64_t *c = d.ctr + (size_t)g * 8;
+        c[4] += 1;
+        c[5] += 1;
+        c[7] += (uint64_t)(ply + 1);
+        int next = lid + d.n_slots;
+        if (next < d.n_games_target) {
+            dc_reset_slot(d, E, g, next, DragonChess::initial());
+            d.sims_left[g] = d.sims_per_move;
+        } else {
+            d.game_lid[g] = -1;
+            d.sims_left[g] = 0;
+        }
+    }
+}
+
+// MCTS.SampleValue rollouts for DragonChess: one wave per leaf (lane = from-square), capped at 2048 plies
+__global__ void __launch_bounds__(256) k_dc_rollout(int n, const DCState *st, const uint32_t *game_id, const int32_t *sim_serial,
+                                                    const int32_t *pend_leaf, uint64_t seed, float *value) {
+    int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (i >= n) return;
+    if (pend_leaf && pend_leaf[i] < 0) return;
+    DCState s = st[i];
+    int player = s.prev;
+    int w = DragonChess::winner(s, -1);
+    uint32_t serial = (uint32_t)(sim_serial[i] - 1);
+    for (uint32_t step = 0; w < 0 && step < 2048; step++) {
+        uint64_t m = DragonChess::targets(s, lane);
+        int cnt = bb_popc64(m), pre = wave_excl_scan_i(cnt, lane), total = wave_sum_i(cnt);
+        if (total == 0) break;
+        Philox4 r = philox4x32_10(seed, game_id[i], serial, BB_TAG_ROLL, step);
+        int pick = (int)(((uint64_t)r.x[0] * (uint64_t)total) >> 32);
+        int a = -1;
+        if (pick >= pre && pick < pre + cnt) {
+            uint64_t mm = m;
+            for (int j = pick - pre; j > 0; j--) mm &= mm - 1;
+            a = DragonChess::action_id(lane, bb_ctz64(mm));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a = max(a, __shfl_xor(a, o, 64));
+        DragonChess::apply(s, a);
+        w = DragonChess::winner(s, a);
+    }
+    if (lane == 0) value[i] = w <= 0 ? 0.5f : (player == w ? 1.0f : 0.0f);
+}

@@ -10,7 +10,25 @@ import pytest
 from blackbird_amd import _lib
 
 pytestmark = pytest.mark.gpu
-GAMES = {"c4": (_lib.GAME_CONNECT4, 0), "ttt": (_lib.GAME_TICTACTOE, 1)}
+GAMES = {"c4": (_lib.GAME_CONNECT4, 0), "ttt": (_lib.GAME_TICTACTOE, 1), "dc": (_lib.GAME_DRAGONCHESS, 2)}
+
+
+def pack_states(game, g):
+    if game == _lib.GAME_DRAGONCHESS:
+        return _lib.pack_dc(g["board"].reshape(-1, 8, 8), g["player"], g["prev"], g["castle"])
+    H, W, _s = _lib.GRID[game]
+    return _lib.pack_grid(game, g["board"].reshape(-1, H, W, 2), g["player"], g["prev"])
+
+
+def same_position(game, a, b):
+    """GameState.__eq__: PreviousPlayer is ignored."""
+    if game == _lib.GAME_DRAGONCHESS:
+        a, b = a.copy(), b.copy()
+        a[:, 65] = 0
+        b[:, 65] = 0
+        return np.array_equal(a[:, :70], b[:, :70])
+    m = np.uint64((1 << 58) - 1)
+    return np.array_equal(a & m, b & m)
 FILES = sorted(os.path.basename(p) for p in glob.glob(
     os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mcts_*.npz"))
     if os.path.basename(p).split("_")[1] in GAMES)
@@ -21,29 +39,42 @@ def test_find_move_golden(golden_dir, fname):
     g = np.load(os.path.join(golden_dir, fname), allow_pickle=False)
     key = fname.split("_")[1]
     game, _ = GAMES[key]
-    H, W, _s = _lib.GRID[game]
     A = _lib.game_info(game).A
+    dc = game == _lib.GAME_DRAGONCHESS
+    cells = 64 if dc else _lib.GRID[game][0] * _lib.GRID[game][1]
     sims, seed, salt, max_depth, fixed, reuse = [int(x) for x in g["meta"]]
     c, temp = [float(x) for x in g["cfg"]]
     gs = g["game_start"]
     ng = len(gs) - 1
     lens = np.diff(gs)
-    st_all = _lib.pack_grid(game, g["board"].reshape(-1, H, W, 2), g["player"], g["prev"])
+    st_all = pack_states(game, g)
     eng = _lib.Engine(game, n_slots=ng, sims_per_move=sims, mcts_kind=_lib.MCTS_FIXED if fixed else _lib.MCTS_DYNAMIC,
                       max_depth=max_depth, evaluator=_lib.EVAL_HASH, c_puct=c, hash_salt=salt, salt_per_game=True,
-                      node_capacity=sims * (H * W + 1) * (max_depth if fixed else 1) + 8)
+                      node_capacity=sims * (cells + 1) * (max_depth if fixed else 1) + 8)
     eng.set_roots(st_all[gs[:-1]], game_ids=np.arange(ng))
     for ply in range(int(lens.max())):
         live = lens > ply
         idx = gs[:-1] + np.minimum(ply, lens - 1)
         # FindMove asserts Root.State == state: the engine's root must be the fixture's position
         roots = eng.root_states()
-        m = np.uint64((1 << 58) - 1)  # __eq__ ignores PreviousPlayer
-        assert np.array_equal(roots[live] & m, st_all[idx][live] & m)
+        assert same_position(game, roots[live], st_all[idx][live])
         eng.run_sims(sims)
         out = eng.sample_moves(temp, u=g["u"][idx])
         for s in np.where(live)[0]:
             i = idx[s]
+            if dc:  # compact child lists: (action, plays) pairs in ascending action order
+                k = int((g["plays"][i][:, 0] >= 0).sum())
+                assert np.array_equal(out["child_action"][s, :k], g["plays"][i][:k, 0].astype(np.int32)), (fname, s, ply)
+                assert (out["child_action"][s, k:] == -1).all()
+                plays = out["child_plays"][s, :k].astype(np.float64)
+                assert np.array_equal(plays, g["plays"][i][:k, 1]), (fname, s, ply)
+                n32 = out["child_plays"][s, :k].astype(np.float32)
+                wr = np.where(n32 > 0, out["child_value"][s, :k] / np.maximum(n32, 1), 0).astype(np.float64)
+                assert np.array_equal(wr, g["winrates"][i][:k])
+                assert out["root_plays"][s] == g["root_plays"][i] and float(out["root_winrate"][s]) == g["v"][i]
+                assert out["action"][s] == g["action"][i], (fname, s, ply)
+                assert np.array_equal(plays / plays.sum(), g["prob"][i][:k])
+                continue
             plays = out["child_plays"][s, :A].astype(np.float64)
             assert np.array_equal(plays, g["plays"][i]), (fname, s, ply, plays, g["plays"][i])
             n32 = out["child_plays"][s, :A].astype(np.float32)
@@ -148,3 +179,34 @@ def test_error_mapping():
     eng.close()
     with pytest.raises(ValueError):
         _lib.Engine(game, n_slots=2, sims_per_move=8, mcts_kind=_lib.MCTS_FIXED, max_depth=0)  # FixedMCTS.py:15
+
+
+def test_dc_selfplay_vs_oracle(orc):
+    """DragonChess (compact child lists, double-move turn order): batched self-play == oracle, example by example."""
+    game = _lib.GAME_DRAGONCHESS
+    n_games, sims, cap = 12, 20, 40
+    eng = _lib.Engine(game, n_slots=8, sims_per_move=sims, evaluator=_lib.EVAL_HASH, hash_salt=555, seed=7,
+                      max_games=n_games, max_plies=cap)
+    eng.selfplay_begin(n_games, 1.0)
+    guard = 0
+    while not eng.selfplay_done()[0]:
+        eng.selfplay_step(4)
+        guard += 1
+        assert guard < 100
+    rec, offs, win = eng.fetch_examples()
+    assert eng.counters()["overflow"] == 0
+    cfg = orc.make_cfg(orc.DC, evaluator=orc.EVAL_HASH, salt=555, seed=7)
+    for gidx in range(n_games):
+        o = orc.selfplay_game(cfg, gidx, 1.0, sims, cap)
+        r = rec[offs[gidx]:offs[gidx + 1]]
+        assert len(r) == o["n"], (gidx, len(r), o["n"])
+        assert win[gidx] == o["winner"]
+        for k in range(len(r)):
+            pi = np.zeros(4032)
+            nch = int(r["n_children"][k])
+            if r["total"][k] > 0:
+                pi[r["action"][k][:nch]] = r["visits"][k][:nch] / float(r["total"][k])
+            assert np.array_equal(pi, o["pi"][k]), (gidx, k)
+        assert np.array_equal(r["player"], o["player"]) and np.array_equal(r["z"].astype(np.float32), o["z"])
+        assert np.array_equal(_lib.game_encode(game, np.ascontiguousarray(r["state"])), o["boards"])
+    eng.close()

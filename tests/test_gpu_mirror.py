@@ -219,3 +219,42 @@ def test_generate_training_samples_drop_in(tmp_path, monkeypatch, orc):
     Blackbird.TrainWithExamples(model, batchSize=8, learningRate=1e-2)
     assert model.Version == 2 and model.getEvaluation(x) != before
     model.Conn.Close()
+
+
+def test_dragonchess_interface(golden_dir):
+    """DragonChess.BoardState mirror: W,W,B turn order, castle flags, 17-plane encoding, edge cases of SURVEY 8a."""
+    from blackbird_amd import DragonChess
+    cls = DragonChess.BoardState
+    g = np.load(os.path.join(golden_dir, "playouts_dc.npz"), allow_pickle=False)
+    gs = g["game_start"]
+    s = cls()
+    assert s.Player == 1 and s.PreviousPlayer is None and s.LegalMoves == 4032 and s.GameType == "DragonChess"
+    assert [cls.int_to_move[a] for a in np.where(s.LegalActions() == 1)[0]] == \
+        ["4 3", "4 5", "11 19", "11 27", "12 20", "12 28", "13 21", "13 29"]
+    for i in range(gs[0], gs[0] + 30):
+        assert np.array_equal(s.board.astype(np.int8).ravel(), g["board"][i])
+        assert s.Player == g["player"][i] and (s.PreviousPlayer or 0) == g["prev"][i]
+        assert np.array_equal(s.AsInputArray().ravel(), g["enc"][i])
+        assert np.array_equal(np.where(s.LegalActions() == 1)[0], g["legal_idx"][g["legal_off"][i]:g["legal_off"][i + 1]])
+        w = s.Winner()
+        assert (-1 if w is None else w) == g["win_none"][i]
+        t = s.Copy()
+        assert t == s and t.PreviousPlayer == s.PreviousPlayer  # DragonChess.Copy keeps PreviousPlayer
+        t.ApplyAction(int(g["action"][i]))
+        s = t
+    # after White's 11->27, 12->28 it is Black's turn with 20 legal moves
+    s = cls()
+    s.ApplyAction(cls.move_to_int["11 27"])
+    assert s.Player == 1 and s.PreviousPlayer == 1
+    s.ApplyAction(cls.move_to_int["12 28"])
+    assert s.Player == 2 and int(s.LegalActions().sum()) == 20
+    with pytest.raises(ValueError, match="illegal move"):
+        s.ApplyAction(cls.move_to_int["0 1"])
+    # K x k is legal and wins
+    k = cls()
+    k.board[:] = 0
+    k.board[3, 3] = 1
+    k.board[4, 4] = -1
+    assert k.LegalActions()[cls.move_to_int["27 36"]] == 1
+    k.ApplyAction(cls.move_to_int["27 36"])
+    assert k.Winner() == 1

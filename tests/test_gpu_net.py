@@ -50,6 +50,32 @@ def test_net_vs_oracle(orc, game, og, perturb, n):
     eng.close()
 
 
+def test_net_dc_vs_oracle(orc):
+    """DragonChess network: 17 input planes, 8x8, 4032-wide policy head."""
+    game = _lib.GAME_DRAGONCHESS
+    w = W.init_weights(17, 16, 2, 16, 4032, seed=13, perturb=True)
+    flat = W.flatten(w)
+    eng = _lib.Engine(game, n_slots=2, sims_per_move=2, evaluator=_lib.EVAL_NET, max_plies=8)
+    eng.load_weights(flat)
+    rng = np.random.RandomState(5)
+    n = 11
+    boards = np.zeros((n, 8, 8), dtype=np.int8)
+    for i in range(n):
+        m = rng.rand(8, 8) < 0.35
+        boards[i][m] = rng.choice([-6, -5, -4, -3, -2, -1, 1, 2], m.sum())
+    st = _lib.pack_dc(boards, rng.randint(1, 3, n), rng.randint(0, 3, n), rng.randint(0, 2, (n, 4)))
+    planes = _lib.game_encode(game, st)
+    v1, l1, p1 = eng.net_eval(states=st)
+    v2, l2, p2 = eng.net_eval(planes=planes)
+    assert np.array_equal(v1, v2) and np.array_equal(l1, l2) and np.array_equal(p1, p2)
+    ov, ol, op = orc.net_forward(orc.NetWeights(8, 8, 17, 16, 2, 16, 4032, flat), planes)
+    assert np.max(np.abs(v1 - ov)) <= TOL
+    assert np.max(np.abs(l1 - ol) / np.maximum(1.0, np.abs(ol))) <= TOL
+    assert np.max(np.abs(p1 - op)) <= TOL and np.allclose(p1.sum(1), 1.0, atol=1e-4)
+    assert np.mean(l1 == ol) > 0.99
+    eng.close()
+
+
 def test_noise_distribution():
     """Prior noise is Beta(alpha, 1-alpha) per action, mixed with weight eps and renormalised."""
     game = _lib.GAME_CONNECT4
