@@ -142,8 +142,15 @@ def main():
         n_examples_all = None
 
     if rank == 0:
-        evals_per_launch = args.slots
-        achieved = FLOPS_PER_EVAL * evals_per_launch / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
+        mode = eng.selfplay_mode()
+        if mode == 2:
+            # persistent kernel: ONE launch covers the timed region; its FLOPs are the evaluations it performed
+            kernel, launches = "k_selfplay_mega<Connect4> (4 network + 4 tree waves per CU)", max(net_n, 1)
+            flops_per_launch = FLOPS_PER_EVAL * cnt["evals"] / launches
+        else:
+            kernel = "k_net_compact<Connect4,4>" if mode == 1 else "k_net_fused16<Connect4,4>"
+            flops_per_launch = FLOPS_PER_EVAL * cnt["evals"] / (K * args.sims)
+        achieved = flops_per_launch / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
         out = {
             "metric": "selfplay_games_per_sec", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3,
@@ -152,13 +159,16 @@ def main():
             "config": {"workload": "Connect4 7x6, DynamicMCTS 800 sims/move, %d concurrent games per GPU, "
                                    "net R4/F16/D16 fp32, noise alpha 0.2 eps 0.3 (BASELINE configs[1])" % args.slots,
                        "game": "Connect4", "sims_per_move": args.sims, "concurrent_games_per_gpu": args.slots,
-                       "blocks": 4, "filters": 16, "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
-            "node_evals_per_sec": sims / dt, "plies_per_sec": plies / dt, "games_finished": games,
+                       "blocks": 4, "filters": 16, "step": "800 tree+network rounds over all games (one ply in lock-step terms)",
+                       "launch_structure": ["lockstep", "async-rounds", "persistent"][mode],
+                       "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
+            "node_evals_per_sec": sims / dt, "net_evals_per_sec_rank0": cnt["evals"] / dt, "plies_per_sec": plies / dt,
+            "games_finished": games, "terminal_leaf_fraction": cnt["terminal_leaves"] / max(cnt["sims"], 1),
             "mean_leaf_depth": cnt["sum_depth"] / max(cnt["sims"], 1), "overflow": cnt["overflow"],
-            "roofline": {"bound": "mfma", "kernel": "k_net_fused16<Connect4,4>", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": None, "launch_ms_mean": net_ms, "launch_ms_min": net_min_ms,
-                         "launches_timed": net_n, "flops_per_launch": FLOPS_PER_EVAL * evals_per_launch},
+                         "launches_timed": net_n, "flops_per_launch": flops_per_launch},
         }
         if allgather_s is not None:
             out["examples_allgather_s"] = allgather_s

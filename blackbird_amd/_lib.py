@@ -20,7 +20,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_NAN, ERR_CAPACITY, ERR_WEIGHTS = 0, -1, -2,
 EXPORTS = (
     "bb_game_info_get", "bb_last_error", "bb_device_count", "bb_game_legal", "bb_game_apply", "bb_game_winner",
     "bb_game_encode", "bb_game_initial", "bb_create", "bb_destroy", "bb_load_weights", "bb_get_counters",
-    "bb_reset_counters", "bb_synchronize", "bb_set_sims_per_move", "bb_timing_enable", "bb_timing_read", "bb_timing_net", "bb_net_eval", "bb_hash_eval", "bb_set_roots", "bb_run_sims",
+    "bb_reset_counters", "bb_synchronize", "bb_set_sims_per_move", "bb_timing_enable", "bb_timing_read", "bb_timing_net", "bb_selfplay_mode", "bb_net_eval", "bb_hash_eval", "bb_set_roots", "bb_run_sims",
     "bb_sample_moves", "bb_move_roots", "bb_get_root_states", "bb_selfplay_begin", "bb_selfplay_step",
     "bb_selfplay_done", "bb_examples_fetch", "bb_examples_device",
 )
@@ -50,7 +50,7 @@ class Config(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("sims", "sum_depth", "nodes", "terminal_leaves", "games_finished",
-                                           "plies", "overflow", "examples")]
+                                           "plies", "overflow", "examples", "evals")]
 
 
 class BlackbirdHipError(RuntimeError):
@@ -88,6 +88,7 @@ def lib():
     L.bb_timing_enable.argtypes = [vp, ip]
     L.bb_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ip)]
     L.bb_timing_net.argtypes = [vp, ip, ip, ip, C.POINTER(C.c_double)]
+    L.bb_selfplay_mode.argtypes = [vp]
     L.bb_net_eval.argtypes = [vp, ip, vp, vp, vp, vp, vp, ip]
     L.bb_hash_eval.argtypes = [vp, ip, vp, vp, vp]
     L.bb_set_roots.argtypes = [vp, ip, vp, vp, vp]
@@ -317,6 +318,9 @@ class Engine:
         m, mn, c = C.c_double(), C.c_double(), C.c_int()
         check(lib().bb_timing_read(self.h, C.byref(m), C.byref(mn), C.byref(c)))
         return m.value, mn.value, c.value
+
+    def selfplay_mode(self):
+        return check(lib().bb_selfplay_mode(self.h))
 
     def timing_net(self, iters=50, noise=True, ablate=0):
         ms = C.c_double()

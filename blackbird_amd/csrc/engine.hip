@@ -7,6 +7,7 @@
 #include "net.hip.h"
 #include "tree.hip.h"
 #include "tree_dc.hip.h"
+#include "mega.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -189,11 +190,28 @@ struct bb_engine {
     double *d_u = nullptr;
     int32_t *d_actions = nullptr;
     // optional HIP-event timing of the evaluator launches
+    // pipelined asynchronous self-play: slot-range views of `dev`, one HIP stream each, so that one
+    // group's (latency-bound) tree kernel runs underneath the other group's (MFMA-bound) network kernel
+    int n_views = 1;
+    TreeDev view[2];
+    hipStream_t vstream[2] = {nullptr, nullptr};
+    int vround[2] = {0, 0};
+    bool mega = false; // persistent per-CU self-play kernel (mega.hip.h)
+    bool async_selfplay = false; // dense games, DynamicMCTS, deterministic evaluators: k_tree_async rounds
+    int round = 0;
     int time_every = 0;
     uint64_t eval_launches = 0;
     std::vector<hipEvent_t> ev_pool; // pairs (start, stop)
     size_t ev_used = 0;
 };
+
+static hipError_t sync_all(bb_engine *e) {
+    if (e->vstream[1]) {
+        hipError_t r = hipStreamSynchronize(e->vstream[1]);
+        if (r != hipSuccess) return r;
+    }
+    return hipStreamSynchronize(e->stream);
+}
 
 template <class T>
 static int dalloc(bb_engine *e, T *&p, size_t count, bool zero = true) {
@@ -224,10 +242,11 @@ static int engine_alloc(bb_engine *e) {
         dalloc(e, d.path_len, n) || dalloc(e, d.game_lid, n) || dalloc(e, d.sim_serial, n) ||
         dalloc(e, d.root_W, n) || dalloc(e, d.root_pp, n) || dalloc(e, d.path, n * G::MAXPATH) ||
         dalloc(e, d.leaf_game_id, n) || dalloc(e, d.leaf_serial, n) || dalloc(e, d.eval_value, n) ||
-        dalloc(e, d.eval_policy, n * PSTRIDE) || dalloc(e, d.ctr, n * 8) || dalloc(e, d.out_action, n) ||
+        dalloc(e, d.eval_policy, n * PSTRIDE) || dalloc(e, d.ctr, n * 8) || dalloc(e, d.evals, n) || dalloc(e, d.out_action, n) ||
         dalloc(e, d.out_root_plays, n) || dalloc(e, d.out_child_plays, n * G::S) ||
         dalloc(e, d.out_root_winrate, n) || dalloc(e, d.out_child_value, n * G::S) || dalloc(e, e->d_u, n) ||
-        dalloc(e, e->d_actions, n) || dalloc(e, d.stamps, 8))
+        dalloc(e, e->d_actions, n) || dalloc(e, d.stamps, 8) || dalloc(e, d.resume_cur, n) ||
+        dalloc(e, d.resume_depth, n) || dalloc(e, d.post_count, 8) || dalloc(e, d.post_slot, n))
         return BB_ERR_HIP;
     typename G::State *ls;
     if (dalloc(e, ls, n)) return BB_ERR_HIP;
@@ -255,8 +274,33 @@ static int engine_alloc(bb_engine *e) {
     // every slot idle until roots are set / self-play begins
     HIPCHK(hipMemsetAsync(d.game_lid, 0xFF, n * 4, e->stream));
     HIPCHK(hipMemsetAsync(d.pend_leaf, 0xFF, n * 4, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemsetAsync(d.resume_cur, 0xFF, n * 4, e->stream));
+    HIPCHK(sync_all(e));
     return BB_OK;
+}
+
+// Slot-range views for pipelined self-play: every per-slot pointer is advanced by the view's first slot.
+template <class G>
+static void make_views(bb_engine *e) {
+    const TreeDev &d = e->dev;
+    int n = d.n_slots;
+    for (int v = 0; v < e->n_views; v++) {
+        TreeDev w = d;
+        int off = v == 0 ? 0 : n / 2;
+        int cnt = e->n_views == 1 ? n : (v == 0 ? n / 2 : n - n / 2);
+        w.n_slots = cnt;
+        w.slot_offset = off;
+        w.root += off; w.root_N += off; w.n_nodes += off; w.ply += off; w.sims_left += off; w.pend_leaf += off;
+        w.pend_expand += off; w.path_len += off; w.game_lid += off; w.sim_serial += off; w.root_W += off;
+        w.root_pp += off; w.path += (size_t)off * G::MAXPATH;
+        w.leaf_state = (char *)d.leaf_state + (size_t)off * sizeof(typename G::State);
+        w.leaf_game_id += off; w.leaf_serial += off; w.eval_value += off;
+        w.eval_policy += (size_t)off * (G::GID == BB_GAME_DRAGONCHESS ? G::A : G::S);
+        w.evals += off; w.ctr += (size_t)off * 8;
+        w.nodes = (char *)d.nodes + (size_t)off * d.node_cap * e->node_bytes;
+        w.resume_cur += off; w.resume_depth += off; w.post_slot += off; w.post_count += 4 * v;
+        e->view[v] = w;
+    }
 }
 
 extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
@@ -300,6 +344,18 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     d.node_cap = (int)cap;
     d.example_bytes = e->info.example_bytes;
     d.gpw = 64 / e->info.S;
+    d.level_budget = 20; // measured optimum on MI355X, Connect4 @800 sims (profiles/README.md)
+    d.slot_offset = 0;
+    d.lid_stride = cfg->n_slots;
+    if (const char *env = getenv("BB_LEVEL_BUDGET")) {
+        int v = atoi(env);
+        if (v >= 1) d.level_budget = v;
+    }
+    e->async_selfplay = cfg->game != BB_GAME_DRAGONCHESS && cfg->mcts_kind == BB_MCTS_DYNAMIC &&
+                        cfg->evaluator != BB_EVAL_ROLLOUT;
+    if (const char *env = getenv("BB_ASYNC")) e->async_selfplay = e->async_selfplay && atoi(env) != 0;
+    e->mega = e->async_selfplay && cfg->evaluator == BB_EVAL_NET;
+    if (const char *env = getenv("BB_MEGA")) e->mega = e->mega && atoi(env) != 0;
     if (const char *env = getenv("BB_TREE_GPW")) {
         int v = atoi(env);
         if (v >= 1 && v <= 64 / e->info.S) d.gpw = v;
@@ -310,6 +366,12 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
         bb_destroy(e);
         return rc;
     }
+    e->n_views = 1;
+    if (e->async_selfplay && !e->mega && cfg->evaluator == BB_EVAL_NET && cfg->n_slots >= 512) e->n_views = 2;
+    if (const char *env = getenv("BB_GROUPS")) e->n_views = (atoi(env) == 2 && e->async_selfplay && cfg->n_slots >= 2) ? 2 : 1;
+    e->vstream[0] = e->stream;
+    if (e->n_views == 2) HIPCHK(hipStreamCreateWithFlags(&e->vstream[1], hipStreamNonBlocking));
+    GAME_SWITCH(cfg->game, make_views<G>(e); break);
     *out = e;
     return BB_OK;
 }
@@ -320,6 +382,10 @@ extern "C" int bb_destroy(bb_engine *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (void *p : e->allocs) (void)hipFree(p);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->vstream[1]) {
+        (void)hipStreamSynchronize(e->vstream[1]);
+        (void)hipStreamDestroy(e->vstream[1]);
+    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return BB_OK;
@@ -328,7 +394,7 @@ extern "C" int bb_destroy(bb_engine *e) {
 extern "C" int bb_timing_enable(bb_engine *e, int every_n) {
     if (!e || every_n < 0) return fail(BB_ERR_ARG, "bad arguments");
     HIPCHK(hipSetDevice(e->cfg.device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(sync_all(e));
     if (every_n > 0 && e->ev_pool.empty()) {
         e->ev_pool.resize(2 * 512);
         for (auto &ev : e->ev_pool) HIPCHK(hipEventCreate(&ev));
@@ -342,7 +408,7 @@ extern "C" int bb_timing_enable(bb_engine *e, int every_n) {
 extern "C" int bb_timing_read(bb_engine *e, double *mean_ms_out, double *min_ms_out, int *count_out) {
     if (!e) return fail(BB_ERR_ARG, "null engine");
     HIPCHK(hipSetDevice(e->cfg.device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(sync_all(e));
     double sum = 0.0, mn = 1e30;
     int cnt = 0;
     for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
@@ -360,9 +426,15 @@ extern "C" int bb_timing_read(bb_engine *e, double *mean_ms_out, double *min_ms_
     return BB_OK;
 }
 
+extern "C" int bb_selfplay_mode(bb_engine *e) {
+    if (!e) return fail(BB_ERR_ARG, "null engine");
+    return e->mega ? 2 : (e->async_selfplay ? 1 : 0);
+}
+
 extern "C" int bb_synchronize(bb_engine *e) {
     if (!e) return fail(BB_ERR_ARG, "null engine");
-    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->vstream[1]) HIPCHK(hipStreamSynchronize(e->vstream[1]));
+    HIPCHK(sync_all(e));
     return BB_OK;
 }
 
@@ -488,7 +560,7 @@ static int net_eval(bb_engine *e, int n, const void *states, const int8_t *plane
                            states ? nullptr : (const int8_t *)din.p, nullptr, nullptr, noise, (float *)dv.p,
                            (float *)dl.p, (float *)dp.p, A, e->stream);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(sync_all(e));
     if (value) HIPCHK(hipMemcpy(value, dv.p, (size_t)n * 4, hipMemcpyDefault));
     if (logits) HIPCHK(hipMemcpy(logits, dl.p, (size_t)n * A * 4, hipMemcpyDefault));
     if (policy) HIPCHK(hipMemcpy(policy, dp.p, (size_t)n * A * 4, hipMemcpyDefault));
@@ -516,7 +588,7 @@ static int hash_eval(bb_engine *e, int n, const void *states, float *value, floa
         k_hash_eval<G><<<nblk(n), 256, 0, e->stream>>>(n, (const typename G::State *)ds.p, nullptr, e->cfg.hash_salt, 0, 0,
                                                        (float *)dv.p, (float *)dp.p, G::A);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(sync_all(e));
     if (value) HIPCHK(hipMemcpy(value, dv.p, (size_t)n * 4, hipMemcpyDefault));
     if (policy) HIPCHK(hipMemcpy(policy, dp.p, (size_t)n * G::A * 4, hipMemcpyDefault));
     return BB_OK;
@@ -614,7 +686,7 @@ static int set_roots(bb_engine *e, int n, const int32_t *slots, const void *stat
         k_set_roots<G><<<nblk(n), 256, 0, e->stream>>>(e->dev, n, slots ? (const int32_t *)dsl.p : nullptr,
                                                        (const typename G::State *)ds.p, gids ? (const uint32_t *)dg.p : nullptr);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(sync_all(e));
     return BB_OK;
 }
 
@@ -658,7 +730,7 @@ static int sample_moves(bb_engine *e, double temp, const double *u, int32_t *act
     else
         k_sample<G><<<nblk(n * G::S), 256, 0, e->stream>>>(d, temp);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(sync_all(e));
     if (action) HIPCHK(hipMemcpy(action, d.out_action, n * 4, hipMemcpyDefault));
     if (wr) HIPCHK(hipMemcpy(wr, d.out_root_winrate, n * 4, hipMemcpyDefault));
     if (rp) HIPCHK(hipMemcpy(rp, d.out_root_plays, n * 4, hipMemcpyDefault));
@@ -694,7 +766,7 @@ extern "C" int bb_move_roots(bb_engine *e, const int32_t *actions) {
         else
             k_move_roots<G><<<nblk((size_t)e->dev.n_slots * G::S), 256, 0, e->stream>>>(e->dev, e->d_actions);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(sync_all(e));
         return BB_OK;
     });
 }
@@ -711,7 +783,7 @@ extern "C" int bb_get_root_states(bb_engine *e, void *states_out) {
         else
             k_get_roots<G><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, (typename G::State *)ds.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(sync_all(e));
         HIPCHK(hipMemcpy(states_out, ds.p, bytes, hipMemcpyDefault));
         return BB_OK;
     });
@@ -723,11 +795,14 @@ extern "C" int bb_set_sims_per_move(bb_engine *e, int sims) {
     if (e->cfg.node_capacity <= 0 && sims > e->cfg.sims_per_move && need > e->dev.node_cap)
         return fail(BB_ERR_CAPACITY, "node pool was sized for %d simulations per move", e->cfg.sims_per_move);
     HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(sync_all(e));
     e->sims_now = sims;
     e->dev.sims_per_move = sims;
+    for (int v = 0; v < e->n_views; v++) e->view[v].sims_per_move = sims;
     GAME_SWITCH(e->cfg.game, {
         k_add_sims<typename std::conditional<G::GID == BB_GAME_DRAGONCHESS, Connect4, G>::type><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, sims); // slots waiting for their next move
         HIPCHK(hipGetLastError());
+        HIPCHK(sync_all(e));
         return BB_OK;
     });
 }
@@ -746,15 +821,79 @@ extern "C" int bb_selfplay_begin(bb_engine *e, int n_games, double temp) {
     e->n_games_target = n_games;
     e->dev.n_games_target = n_games;
     e->dev.temp = temp;
+    HIPCHK(sync_all(e));
     HIPCHK(hipMemsetAsync(e->dev.game_hdr, 0, (size_t)e->cfg.max_games * 16, e->stream));
+    HIPCHK(hipMemsetAsync(e->dev.resume_cur, 0xFF, (size_t)e->dev.n_slots * 4, e->stream));
+    HIPCHK(hipMemsetAsync(e->dev.post_count, 0, 8 * sizeof(int), e->stream));
+    HIPCHK(sync_all(e));
+    e->vround[0] = e->vround[1] = 0;
     GAME_SWITCH(e->cfg.game, {
-        if constexpr (G::GID == BB_GAME_DRAGONCHESS)
+        if constexpr (G::GID == BB_GAME_DRAGONCHESS) {
             k_dc_selfplay_begin<<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, e->edges);
-        else
-            k_selfplay_begin<G><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev);
+        } else {
+            for (int v = 0; v < e->n_views; v++) {
+                e->view[v].n_games_target = n_games;
+                e->view[v].temp = temp;
+                e->view[v].sims_per_move = e->sims_now;
+                k_selfplay_begin<G><<<nblk(e->view[v].n_slots), 256, 0, e->vstream[v]>>>(e->view[v]);
+            }
+        }
         HIPCHK(hipGetLastError());
         return BB_OK;
     });
+}
+
+template <class G>
+static int selfplay_rounds_async(bb_engine *e, int rounds) {
+    if constexpr (G::GID == BB_GAME_DRAGONCHESS) {
+        return fail(BB_ERR_ARG, "asynchronous self-play is for the dense-action games");
+    } else {
+        constexpr int PWMAX = NetPW<G>::v;
+        if (e->mega) { // one persistent launch: `rounds` visits of every game == 2*rounds phases
+            TreeDev &d = e->dev;
+            int nb = (d.n_slots + 15) / 16;
+            bool timed = e->time_every > 0 && e->ev_used + 2 <= e->ev_pool.size();
+            if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
+            k_selfplay_mega<G><<<nb, 512, 0, e->stream>>>(d, e->net, 2 * rounds, e->cfg.noise_on);
+            HIPCHK(hipGetLastError());
+            if (timed) {
+                HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
+                e->ev_used += 2;
+            }
+            return BB_OK;
+        }
+        for (int r = 0; r < rounds; r++) {
+            for (int v = 0; v < e->n_views; v++) {
+                TreeDev &d = e->view[v];
+                hipStream_t st = e->vstream[v];
+                int tb = nblk((size_t)((d.n_slots + d.gpw - 1) / d.gpw) * 64);
+                int nb = (d.n_slots + 4 * PWMAX - 1) / (4 * PWMAX);
+                if (e->n_views == 2) nb = 256 > nb ? 256 : nb; // spread a half batch over every CU (pw <= 2)
+                int round = e->vround[v]++;
+                k_tree_async<G><<<tb, 256, 0, st>>>(d, round);
+                HIPCHK(hipGetLastError());
+                const typename G::State *ls = (const typename G::State *)d.leaf_state;
+                if (d.evaluator == BB_EVAL_NET) {
+                    bool timed = v == 0 && e->time_every > 0 && (e->eval_launches++ % (uint64_t)e->time_every) == 0 &&
+                                 e->ev_used + 2 <= e->ev_pool.size();
+                    if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], st));
+                    k_net_compact<G, PWMAX><<<nb, 256, 0, st>>>(e->net, d.post_count + (round & 3), d.post_slot, ls,
+                                                                 d.leaf_game_id, d.leaf_serial, e->cfg.noise_on, d.eval_value,
+                                                                 d.eval_policy, G::S);
+                    HIPCHK(hipGetLastError());
+                    if (timed) {
+                        HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], st));
+                        e->ev_used += 2;
+                    }
+                } else { // validation evaluator over every slot's mailbox of the view
+                    k_hash_eval<G><<<nblk(d.n_slots), 256, 0, st>>>(d.n_slots, ls, d.leaf_game_id, d.salt, d.salt_per_game,
+                                                                    d.first_game_id, d.eval_value, d.eval_policy, G::S);
+                    HIPCHK(hipGetLastError());
+                }
+            }
+        }
+        return BB_OK;
+    }
 }
 
 extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
@@ -762,6 +901,7 @@ extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
     if (e->n_games_target <= 0) return fail(BB_ERR_ARG, "bb_selfplay_begin has not been called");
     HIPCHK(hipSetDevice(e->cfg.device));
     GAME_SWITCH(e->cfg.game, {
+        if (e->async_selfplay) return selfplay_rounds_async<G>(e, plies * e->sims_now);
         for (int p = 0; p < plies; p++) {
             int rc = run_sims<G>(e, e->sims_now);
             if (rc) return rc;
@@ -775,22 +915,17 @@ extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
     });
 }
 
-#ifdef BB_STAMPS
-extern "C" int bb_debug_stamps(bb_engine *e, unsigned long long *out8) {
-    HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(out8, e->dev.stamps, 64, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(e->dev.stamps, 0, 64));
-    return BB_OK;
-}
-#endif
-
 static int sum_counters(bb_engine *e, bb_counters *out) {
     size_t n = (size_t)e->dev.n_slots * 8;
     std::vector<uint64_t> h(n);
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(sync_all(e));
     HIPCHK(hipMemcpy(h.data(), e->dev.ctr, n * 8, hipMemcpyDeviceToHost));
     uint64_t t[8] = {0};
     for (size_t i = 0; i < n; i++) t[i & 7] += h[i];
+    std::vector<uint64_t> ev((size_t)e->dev.n_slots);
+    HIPCHK(hipMemcpy(ev.data(), e->dev.evals, ev.size() * 8, hipMemcpyDeviceToHost));
+    out->evals = 0;
+    for (uint64_t v : ev) out->evals += v;
     out->sims = t[0];
     out->sum_depth = t[1];
     out->nodes = t[2];
@@ -812,13 +947,14 @@ extern "C" int bb_reset_counters(bb_engine *e) {
     if (!e) return fail(BB_ERR_ARG, "null engine");
     HIPCHK(hipSetDevice(e->cfg.device));
     HIPCHK(hipMemsetAsync(e->dev.ctr, 0, (size_t)e->dev.n_slots * 64, e->stream));
+    HIPCHK(hipMemsetAsync(e->dev.evals, 0, (size_t)e->dev.n_slots * 8, e->stream));
     return BB_OK;
 }
 
 extern "C" int bb_selfplay_done(bb_engine *e, int *done_out, int *games_finished_out) {
     if (!e) return fail(BB_ERR_ARG, "null engine");
     HIPCHK(hipSetDevice(e->cfg.device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(sync_all(e));
     int ng = e->n_games_target;
     std::vector<int32_t> h((size_t)ng * 4);
     if (ng) HIPCHK(hipMemcpy(h.data(), e->dev.game_hdr, h.size() * 4, hipMemcpyDeviceToHost));
@@ -834,7 +970,7 @@ extern "C" int bb_examples_fetch(bb_engine *e, int first_game, int n_games, void
     if (!e || first_game < 0 || n_games <= 0 || first_game + n_games > e->cfg.max_games || !records_out)
         return fail(BB_ERR_ARG, "bad arguments");
     HIPCHK(hipSetDevice(e->cfg.device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(sync_all(e));
     const size_t eb = (size_t)e->info.example_bytes, per = (size_t)(e->cfg.max_plies + 1) * eb;
     std::vector<int32_t> hdr((size_t)n_games * 4);
     HIPCHK(hipMemcpy(hdr.data(), e->dev.game_hdr + (size_t)first_game * 4, hdr.size() * 4, hipMemcpyDeviceToHost));

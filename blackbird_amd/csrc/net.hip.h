@@ -47,34 +47,48 @@ struct NetGeom {
     static constexpr int NT = (PW * HW + 15) / 16;     // 16-pixel tiles per wave
     static constexpr int STEPS0 = (9 * CIN + 3) / 4;   // MFMA k-steps of the first conv
     static constexpr int ACT = PW * SLOTS * 16;        // floats per activation buffer
-    static constexpr int WAVE_FLOATS = 2 * ACT + PW * SLOTS * CP;
+    static constexpr int STATE_FLOATS = (PW * (int)sizeof(typename G::State) + 15) / 16 * 4; // packed boards staged in LDS
+    static constexpr int WAVE_FLOATS = 2 * ACT + PW * SLOTS * CP + STATE_FLOATS;
     static constexpr int LDS_BYTES = 4 * WAVE_FLOATS * 4;
     static_assert(LDS_BYTES <= 163840, "activations must fit the 160 KiB LDS");
 };
 
+// The whole network for the PW positions [pos0, pos0+PW) of a batch of n, computed by ONE wave in its
+// own LDS region `wlds` (NetGeom<G,PW>::WAVE_FLOATS floats).  slot_list != nullptr: batch entry i is
+// engine slot slot_list[i] (inputs are read from, and outputs written to, that slot's mailbox).
 template <class G, int PW>
-__global__ void __launch_bounds__(256, 1)
-k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *planes,
-              const uint32_t *game_id, const int32_t *serial, int noise, float *value_out, float *logits_out,
-              float *policy_out, int pstride) {
+__device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, const int *slot_list, float *wlds,
+                                         const typename G::State *states, const int8_t *planes,
+                                         const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
+                                         float *logits_out, float *policy_out, int pstride, bool zero_lds = true) {
     using NG = NetGeom<G, PW>;
     constexpr int W = NG::W, CIN = NG::CIN, A = NG::A, HW = NG::HW, SLOTS = NG::SLOTS, CP = NG::CP,
                   NT = NG::NT, STEPS0 = NG::STEPS0, ACT = NG::ACT;
-    __shared__ __attribute__((aligned(16))) float lds[4 * NG::WAVE_FLOATS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int j = lane >> 4, nn = lane & 15;
-    float *actA = lds + wave * NG::WAVE_FLOATS;
+    float *actA = wlds;
     float *actB = actA + ACT;
     float *inp = actB + ACT;
-    const int pos0 = (blockIdx.x * 4 + wave) * PW;
-    if (pos0 >= n) return; // whole wave idle (no block-level sync anywhere below)
+    auto OI = [&](int pos) { return slot_list ? slot_list[pos] : pos; };
 
+    // ---- issue every global load of the prologue first, then zero LDS while they are in flight ---------
+    // (one packed board per lane, the first conv's weights and epilogue constants)
+    const int my_pp = lane % PW;
+    const typename G::State my_state = planes ? G::initial() : states[OI(pos0 + my_pp < n ? pos0 + my_pp : pos0)];
+    float w0r[STEPS0];
+#pragma unroll
+    for (int s = 0; s < STEPS0; s++) w0r[s] = nd.w0[s * 64 + lane];
+    const f32x4 bias0 = *(const f32x4 *)(nd.epi + 4 * j), scale0 = *(const f32x4 *)(nd.epi + 16 + 4 * j),
+                shift0 = *(const f32x4 *)(nd.epi + 32 + 4 * j);
     // ---- zero this wave's LDS (halo pixels must read as 0 forever) --------------------------
-    {
+    if (zero_lds) { // a persistent caller zeroes once: halos are never written, interiors are always rewritten
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         f32x4 *p = (f32x4 *)actA;
         for (int i = lane; i < NG::WAVE_FLOATS / 4; i += 64) p[i] = z;
     }
+    // the PW boards go through LDS so that every lane can decode any cell of any position
+    typename G::State *sst = (typename G::State *)(inp + PW * SLOTS * CP);
+    if (!planes && lane < PW) sst[lane] = my_state;
     // ---- input planes -> inp[pos][slot][CP] ---------------------------------------------------
     for (int q = lane; q < PW * HW; q += 64) {
         int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
@@ -87,7 +101,7 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
             for (int c = 0; c < CIN; c++) dst[c] = (float)src[c];
         } else {
             int8_t v[CIN];
-            G::encode_cell(states[pos], y, x, v);
+            G::encode_cell(sst[pp], y, x, v);
 #pragma unroll
             for (int c = 0; c < CIN; c++) dst[c] = (float)v[c];
         }
@@ -109,9 +123,7 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
     f32x4 acc[NT];
     // ---- first conv: K = 9*CIN in natural (tap, c) order, 4 k per MFMA ---------------------------
     {
-        const float *ep = nd.epi;
-        f32x4 bias = *(const f32x4 *)(ep + 4 * j), scale = *(const f32x4 *)(ep + 16 + 4 * j),
-              shift = *(const f32x4 *)(ep + 32 + 4 * j);
+        const f32x4 bias = bias0, scale = scale0, shift = shift0;
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = bias;
 #pragma unroll
@@ -120,7 +132,7 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
             int kk = k < 9 * CIN ? k : 9 * CIN - 1; // padded k: weight is 0, any readable address will do
             int tap = kk / CIN, c = kk % CIN;
             int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * CP + c;
-            float a = nd.w0[s * 64 + lane];
+            float a = w0r[s];
 #pragma unroll
             for (int t = 0; t < NT; t++) {
                 float b = inp[ioff[t] + toff];
@@ -176,7 +188,7 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
         }
     }
     if (nd.dbg & 1) {
-        if (value_out && lane == 0) value_out[pos0] = acc[0][0];
+        if (value_out && lane == 0) value_out[OI(pos0)] = acc[0][0];
         return;
     }
     // ---- heads (tower output is in actA; actB and inp are scratch now) --------------------------
@@ -213,6 +225,7 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
         for (int q = lane; q < PW * D; q += 64) { // dense_1 per pixel, then reduce_sum over H,W, ReLU
             int pp = q / D, dd = q % D;
             float s = 0.f, wk = d1k[dd], wb = d1b[dd];
+#pragma unroll
             for (int p = 0; p < HW; p++) s += __builtin_fmaf(rv[pp * HW + p], wk, wb);
             sd[q] = fmaxf(s, 0.f);
         }
@@ -221,6 +234,7 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
             for (int q = lane; q < PW * A; q += 64) { // policy dense on the last axis, reduce_sum over H,W
                 int pp = q / A, a = q % A;
                 float s = 0.f, k0 = pdk[a], k1 = pdk[A + a], kb = pdb[a];
+#pragma unroll
                 for (int p = 0; p < HW; p++)
                     s += __builtin_fmaf(rp[2 * (pp * HW + p) + 1], k1, __builtin_fmaf(rp[2 * (pp * HW + p)], k0, kb));
                 lg[q] = s;
@@ -234,8 +248,8 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
         const int D = nd.D;
         const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
         for (int pp = 0; pp < PW; pp++) {
-            int pos = pos0 + pp;
-            if (pos >= n) break;
+            if (pos0 + pp >= n) break;
+            int pos = OI(pos0 + pp);
             float *outp = policy_out ? policy_out + (size_t)pos * pstride : nullptr;
             float m = -INFINITY;
             for (int a = lane; a < A; a += 64) {
@@ -269,15 +283,26 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
     }
     if constexpr (A <= 64) {
     float *nz = lg + PW * A; // [PW][A] Beta(alpha, 1-alpha) draws, one lane per (position, action)
-    if (noise)
-        for (int q = lane; q < PW * A; q += 64) {
-            int pp = q / A, a = q % A, pos = pos0 + pp;
-            if (pos >= n) continue;
+    if (noise) { // two lanes per (position, action): lane pair (2i, 2i+1) tries Philox pairs k and k+1 side by side
+        const float ia = 1.0f / nd.alpha, ib = 1.0f / (1.0f - nd.alpha);
+        for (int base = 0; base < PW * A; base += 32) {
+            int q = base + (lane >> 1), sub = lane & 1;
+            bool live = q < PW * A && pos0 + q / A < n;
+            int a = live ? q % A : 0;
+            int pos = live ? OI(pos0 + q / A) : 0;
             uint32_t gid = game_id ? game_id[pos] : (uint32_t)noise, ser = serial ? (uint32_t)serial[pos] : (uint32_t)pos;
-            nz[q] = bb_beta_noise(nd.seed, gid, ser, (uint32_t)a, nd.alpha);
+            float r = (nd.dbg & 8) ? nd.alpha : -1.0f;
+            for (uint32_t k = 0; k < 32 && __any(live && r < 0.0f); k += 2) {
+                float mine = (live && r < 0.0f) ? bb_beta_pair(nd.seed, gid, ser, (uint32_t)a, ia, ib, k + sub) : -1.0f;
+                float other = __shfl_xor(mine, 1, 64);
+                float first = sub ? other : mine, second = sub ? mine : other; // pair k before pair k+1
+                if (r < 0.0f) r = first >= 0.0f ? first : second;
+            }
+            if (live && sub == 0) nz[q] = r >= 0.0f ? r : nd.alpha;
         }
+    }
     if (lane < PW && pos0 + lane < n) { // one lane finishes each position (sequential, oracle order)
-        const int D = nd.D, pp = lane, pos = pos0 + lane;
+        const int D = nd.D, pp = lane, pos = OI(pos0 + lane);
         const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
         float e = d2b[0];
         for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(sd[pp * D + dd], d2k[dd], e);
@@ -309,5 +334,48 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
 #pragma unroll
             for (int a = 0; a < A; a++) policy_out[(size_t)pos * pstride + a] = pr[a];
     }
+    }
+    if (!zero_lds) { // persistent caller: the head scratch overlaid actB's halo slots -- restore the zeros
+        const int used = 3 * PW * HW + PW * nd.D + 2 * PW * (A <= 64 ? A : 0);
+        for (int i = lane; i < used; i += 64) actB[i] = 0.f;
+    }
+}
+
+// fixed PW positions per wave, batch entry i == output index i (bb_net_eval, lock-step search)
+template <class G, int PW>
+__global__ void __launch_bounds__(256, 1)
+k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *planes,
+              const uint32_t *game_id, const int32_t *serial, int noise, float *value_out, float *logits_out,
+              float *policy_out, int pstride) {
+    using NG = NetGeom<G, PW>;
+    __shared__ __attribute__((aligned(16))) float lds[4 * NG::WAVE_FLOATS];
+    const int wave = threadIdx.x >> 6;
+    const int pos0 = (blockIdx.x * 4 + wave) * PW;
+    if (pos0 >= n) return; // whole wave idle (no block-level sync anywhere)
+    net_body<G, PW>(nd, n, pos0, nullptr, lds + wave * NG::WAVE_FLOATS, states, planes, game_id, serial, noise, value_out,
+                    logits_out, policy_out, pstride);
+}
+
+// Compacted batch: *n_ptr leaves were posted this round (slots listed in slot_list).  The grid is always
+// 256 workgroups x 4 waves; the leaves are dealt evenly, pw = ceil(n / 1024) per wave, so a round with
+// fewer fresh leaves runs fewer MFMA tiles per wave instead of leaving CUs idle.
+template <class G, int PWMAX>
+__global__ void __launch_bounds__(256, 1)
+k_net_compact(NetDev nd, const int *n_ptr, const int *slot_list, const typename G::State *states,
+              const uint32_t *game_id, const int32_t *serial, int noise, float *value_out, float *policy_out,
+              int pstride) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * NetGeom<G, PWMAX>::WAVE_FLOATS];
+    const int n = *n_ptr;
+    const int wave = threadIdx.x >> 6, gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    int pw = (n + nw - 1) / nw;
+    if (pw > PWMAX) pw = PWMAX; // host guarantees n <= nw * PWMAX
+    const int pos0 = gw * pw;
+    if (pos0 >= n) return;
+    float *wl = lds + wave * NetGeom<G, PWMAX>::WAVE_FLOATS;
+    switch (pw) {
+    case 1: net_body<G, 1>(nd, n, pos0, slot_list, wl, states, nullptr, game_id, serial, noise, value_out, nullptr, policy_out, pstride); break;
+    case 2: net_body<G, 2>(nd, n, pos0, slot_list, wl, states, nullptr, game_id, serial, noise, value_out, nullptr, policy_out, pstride); break;
+    case 3: net_body<G, 3>(nd, n, pos0, slot_list, wl, states, nullptr, game_id, serial, noise, value_out, nullptr, policy_out, pstride); break;
+    default: net_body<G, PWMAX>(nd, n, pos0, slot_list, wl, states, nullptr, game_id, serial, noise, value_out, nullptr, policy_out, pstride); break;
     }
 }

@@ -66,16 +66,31 @@ __host__ __device__ __forceinline__ float bb_hash_policy(uint64_t z, int a) {
     return (float)(int32_t)(1 + (za >> 44));
 }
 
-// Beta(alpha, 1-alpha) by Johnk's method (NetworkFactory.py:176-180: Dirichlet([a,1-a]) first coordinate)
+// Beta(alpha, 1-alpha) by Johnk's method (NetworkFactory.py:176-180: Dirichlet([a,1-a]) first coordinate):
+// X = U^(1/alpha), Y = V^(1/(1-alpha)); accept when X+Y <= 1; return X/(X+Y).
+// Trial t takes its two uniforms from Philox counter (game, node, 'NOIS', action*64 + t/2), words 2(t&1), 2(t&1)+1.
+// bb_beta_pair evaluates trials 2k and 2k+1 (one Philox call) and returns the first accepted draw, or -1.
+__device__ __forceinline__ float bb_beta_pair(uint64_t key, uint32_t game_id, uint32_t node, uint32_t action, float ia,
+                                              float ib, uint32_t k) {
+    Philox4 r = philox4x32_10(key, game_id, node, BB_TAG_NOISE, action * 64u + k);
+    float out = -1.0f;
+#pragma unroll
+    for (int h = 1; h >= 0; h--) {
+        float u = ((float)(r.x[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        float v = ((float)(r.x[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        // hardware exp2/log2 (v_exp_f32 / v_log_f32): ~1e-6 relative error, far below what a prior-noise draw needs
+        float X = __powf(u, ia), Y = __powf(v, ib);
+        if (X + Y <= 1.0f && X + Y > 0.0f) out = X / (X + Y); // h = 0 (the earlier trial) is written last
+    }
+    return out;
+}
+
 __device__ __forceinline__ float bb_beta_noise(uint64_t key, uint32_t game_id, uint32_t node, uint32_t action,
                                                float alpha) {
     float ia = 1.0f / alpha, ib = 1.0f / (1.0f - alpha);
-    for (uint32_t trial = 0; trial < 64; trial++) {
-        Philox4 r = philox4x32_10(key, game_id, node, BB_TAG_NOISE, action * 64u + trial);
-        float u = ((float)(r.x[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        float v = ((float)(r.x[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        float X = powf(u, ia), Y = powf(v, ib);
-        if (X + Y <= 1.0f && X + Y > 0.0f) return X / (X + Y);
+    for (uint32_t k = 0; k < 32; k++) {
+        float r = bb_beta_pair(key, game_id, node, action, ia, ib, k);
+        if (r >= 0.0f) return r;
     }
     return alpha;
 }

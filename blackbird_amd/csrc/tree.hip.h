@@ -26,6 +26,7 @@
 #endif
 #define NODE_EXPANDED 1
 #define NODE_TERMINAL 2
+#define NODE_CACHED 4 // terminal node whose evaluator value is stored in pad0 (Model.SampleValue's lru_cache)
 #define CHILD_NONE (-1)
 #define CHILD_TERM_BIT 0x40000000
 
@@ -81,6 +82,7 @@ struct TreeDev {
     int32_t *leaf_serial;   // [n_slots]
     float *eval_value;      // [n_slots]
     float *eval_policy;     // [n_slots][S]
+    uint64_t *evals;        // [n_slots] leaves handed to the evaluator
     uint64_t *ctr;          // [n_slots][8]: sims, sum_depth, nodes, terminal, games, plies, overflow, examples
     void *nodes;            // [n_slots][node_cap]
     // self-play
@@ -93,6 +95,14 @@ struct TreeDev {
     int32_t *out_action, *out_root_plays, *out_child_plays;
     float *out_root_winrate, *out_child_value;
     const double *in_u; // optional uniforms
+    // asynchronous self-play (k_tree_async): resumable descents + compacted leaf list
+    int32_t *resume_cur, *resume_depth; // [n_slots] descent parked by the level budget (-1: none)
+    int *post_count;                    // [4] leaves posted in round r -> post_count[r & 3]
+    int *post_slot;                     // [n_slots] slots of the posted leaves, in arrival order
+    int level_budget;                   // tree levels one launch may descend per game
+    // a TreeDev may be a VIEW of a slot range (pointers pre-offset): pipelined self-play runs two views on two streams
+    int slot_offset;                    // first slot of this view in the engine
+    int lid_stride;                     // engine-wide slot count: a slot's next game id is lid + lid_stride
     unsigned long long *stamps; // diagnostic build only (BB_STAMPS): [apply, fence, select, levels, waves]
 };
 
@@ -178,6 +188,33 @@ __device__ __forceinline__ double child_q(const TreeDev &d, float Qi, float Wi, 
     return Ni > 0 ? (double)Wi / (double)Ni : 0.0;
 }
 
+// MCTS._backProp (MCTS.py:238-258): one (parent, action) edge of the recorded path per lane; v01 is the
+// value for `prev` (= leaf.State.PreviousPlayer).  Refreshes Q and sqrt(1+sum N) of the rows it touches.
+template <class G>
+__device__ __forceinline__ void backup_path(const TreeDev &d, int g, int lane, DenseNode<G> *pool, int plen, float v01,
+                                            int prev) {
+    constexpr int S = G::S;
+    float vflip = 1.0f - v01;
+    const uint32_t *path = d.path + (size_t)g * G::MAXPATH;
+    for (int k = lane; k < plen; k += S) {
+        uint32_t e = path[k];
+        int a = e & 15, pl = (e >> 4) & 3;
+        DenseNode<G> *pn = pool + (e >> 6);
+        int n = pn->N[a] + 1, all = pn->all + 1;
+        float w = pn->W[a] + ((pl == prev) ? v01 : vflip);
+        pn->N[a] = n;
+        pn->W[a] = w;
+        pn->Q[a] = __fdiv_rn(w, (float)n);
+        pn->all = all;
+        pn->sq = __dsqrt_rn(1.0 + (double)all);
+    }
+    if (lane == 0) {
+        d.root_N[g] += 1;
+        int pp = d.root_pp[g];
+        if (pp) d.root_W[g] += (pp == prev) ? v01 : vflip;
+    }
+}
+
 // ---- phase A: apply the evaluator's answer for the pending leaf (expand + backup) -------------
 template <class G>
 __device__ void phase_apply(const TreeDev &d, int g, int lane) {
@@ -214,27 +251,12 @@ __device__ void phase_apply(const TreeDev &d, int g, int lane) {
         v01 = (v + 1.0f) * 0.5f; // Model.SampleValue: float32 arithmetic
         if (player != prev) v01 = 1.0f - v01;
     }
-    float vflip = 1.0f - v01;
-    int plen = d.path_len[g];
-    const uint32_t *path = d.path + (size_t)g * G::MAXPATH;
-    for (int k = lane; k < plen; k += S) { // _backProp: one (parent,action) edge per lane
-        uint32_t e = path[k];
-        int a = e & 15, pl = (e >> 4) & 3;
-        Node *pn = pool + (e >> 6);
-        int n = pn->N[a] + 1, all = pn->all + 1;
-        float w = pn->W[a] + ((pl == prev) ? v01 : vflip);
-        pn->N[a] = n;
-        pn->W[a] = w;
-        pn->Q[a] = __fdiv_rn(w, (float)n);
-        pn->all = all;
-        pn->sq = __dsqrt_rn(1.0 + (double)all);
+    if (d.evaluator != 2 && !d.pend_expand[g] && (node->flags & NODE_TERMINAL) && lane == 0) { // remember a terminal leaf's value
+        node->pad0 = (double)v01;
+        node->flags |= NODE_CACHED;
     }
-    if (lane == 0) {
-        d.root_N[g] += 1;
-        int pp = d.root_pp[g];
-        if (pp) d.root_W[g] += (pp == prev) ? v01 : vflip;
-        d.pend_leaf[g] = -1;
-    }
+    backup_path<G>(d, g, lane, pool, d.path_len[g], v01, prev);
+    if (lane == 0) d.pend_leaf[g] = -1;
 }
 
 // allocate + initialise a child node (lane 0 writes).  nn = the slot's allocation cursor (register copy).
@@ -390,6 +412,7 @@ __device__ void phase_select(const TreeDev &d, int g, int lane) {
         d.path_len[g] = depth;
         d.sims_left[g] -= 1;
         d.sim_serial[g] += 1;
+        d.evals[g] += 1;
         uint64_t *c = d.ctr + (size_t)g * 8;
         c[0] += 1;
         c[1] += (uint64_t)depth;
@@ -637,8 +660,8 @@ template <class G>
 __global__ void __launch_bounds__(256) k_selfplay_begin(TreeDev d) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.n_slots) return;
-    if (g < d.n_games_target) {
-        reset_slot<G>(d, g, g, G::initial());
+    if (g + d.slot_offset < d.n_games_target) {
+        reset_slot<G>(d, g, g + d.slot_offset, G::initial());
         d.sims_left[g] = d.sims_per_move;
     } else {
         reset_slot<G>(d, g, -1, G::initial());
@@ -670,15 +693,11 @@ __device__ void write_example(const TreeDev &d, int lid, int ply, const typename
 }
 
 // apply the last pending leaf, then FindMove's tail + the body of GenerateTrainingSamples' while loop
+// FindMove's tail + the body of GenerateTrainingSamples' while loop for one slot (all lanes of the group call)
 template <class G>
-__global__ void __launch_bounds__(256) k_selfplay_move(TreeDev d) {
+__device__ void selfplay_move_body(const TreeDev &d, int g, int lane) {
     using Node = DenseNode<G>;
     constexpr int S = G::S;
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    int g = t / S, lane = t % S;
-    if (g >= d.n_slots) return;
-    phase_apply<G>(d, g, lane);
-    __threadfence_block();
     int lid = d.game_lid[g];
     if (lid < 0) return;
     Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
@@ -728,7 +747,7 @@ __global__ void __launch_bounds__(256) k_selfplay_move(TreeDev d) {
         c[4] += 1;
         c[5] += 1;
         c[7] += (uint64_t)(ply + 1);
-        int next = lid + d.n_slots; // this slot's next game id
+        int next = lid + d.lid_stride; // this slot's next game id
         if (next < d.n_games_target) {
             reset_slot<G>(d, g, next, G::initial());
             d.sims_left[g] = d.sims_per_move;
@@ -736,5 +755,165 @@ __global__ void __launch_bounds__(256) k_selfplay_move(TreeDev d) {
             d.game_lid[g] = -1;
             d.sims_left[g] = 0;
         }
+    }
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_selfplay_move(TreeDev d) {
+    constexpr int S = G::S;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int g = t / S, lane = t % S;
+    if (g >= d.n_slots) return;
+    phase_apply<G>(d, g, lane);
+    __threadfence_block();
+    selfplay_move_body<G>(d, g, lane);
+}
+
+// ---- asynchronous self-play round ------------------------------------------------------------------------
+// Games no longer move in lock-step.  One launch gives every game a budget of tree levels:
+//   apply the evaluated leaf (if any) -> [800 simulations done? sample + move + maybe next game] ->
+//   descend; a terminal leaf whose value is already known (the reference's lru_cache on SampleValue,
+//   Blackbird.py:350) is backed up on the spot and the next simulation starts; the first leaf that needs
+//   the evaluator is posted to the compacted leaf list and the game waits for the network kernel;
+//   a descent that outlives the budget is parked (resume_cur/resume_depth) and continues next launch.
+// Per game the sequence of simulations is exactly the sequential one, so results do not depend on the
+// schedule (tests/test_gpu_mcts.py: self-play == oracle, example by example).
+template <class G>
+__device__ bool async_game(const TreeDev &d, int g, int lane) {
+    using Node = DenseNode<G>;
+    constexpr int S = G::S, A = G::A;
+    if (d.game_lid[g] < 0) return false;
+    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    if (d.pend_leaf[g] >= 0) {
+        phase_apply<G>(d, g, lane);
+        if (lane == 0) d.sims_left[g] -= 1;
+        __threadfence_block();
+    }
+    int budget = d.level_budget;
+    uint32_t *path = d.path + (size_t)g * G::MAXPATH;
+    int sims_done = 0, depth_sum = 0, term_hits = 0;
+    bool posted = false;
+    for (;;) {
+        if (d.sims_left[g] <= 0) { // MCTS.FindMove's tail, GenerateTrainingSamples' loop body
+            selfplay_move_body<G>(d, g, lane);
+            __threadfence_block();
+            if (d.game_lid[g] < 0) break;
+        }
+        int cur = d.resume_cur[g], depth = 0;
+        if (cur >= 0) depth = d.resume_depth[g];
+        else cur = d.root[g];
+        int nn = d.n_nodes[g];
+        typename G::State st;
+        int flags = 0, expand = 0, overflow = 0;
+        bool have = false, parked = false, leaf_found = false, term = false;
+        for (;;) {
+            if (budget <= 0) { parked = true; break; }
+            budget--;
+            Node *node = pool + cur;
+            typename G::State st_l = node->st;
+            int flags_l = node->flags;
+            uint32_t mask = node->legal_mask;
+            double sq = node->sq;
+            int Ni = node->N[lane];
+            float Qi = node->Q[lane];
+            double cPi = node->cP[lane];
+            int ci = node->child[lane];
+            double cached = node->pad0;
+            asm volatile("" ::"v"(flags_l), "v"(mask), "v"(sq), "v"(Ni), "v"(Qi), "v"(cPi), "v"(ci));
+            if (!have) {
+                st = st_l;
+                flags = flags_l;
+            }
+            have = false;
+            if (!(flags & NODE_EXPANDED)) {
+                leaf_found = true;
+                if (flags & NODE_TERMINAL) {
+                    term = true;
+                    if (flags & NODE_CACHED) { // value already known: finish this simulation here
+                        float v01 = (float)cached;
+                        __threadfence_block(); // path stores of this descent
+                        backup_path<G>(d, g, lane, pool, depth, v01, gs_prev(st));
+                        if (lane == 0) d.sims_left[g] -= 1;
+                        __threadfence_block();
+                        sims_done++;
+                        depth_sum += depth;
+                        term_hits++;
+                        leaf_found = false; // nothing to post; start the next simulation
+                    }
+                } else {
+                    expand = 1;
+                }
+                break;
+            }
+            if (mask == 0) { leaf_found = true; break; }
+            double u = puct_score(child_q(d, Qi, 0.f, Ni), cPi, sq, Ni, lane < A && ((mask >> lane) & 1u));
+            int child = ci;
+            int a = grp_argmax<S>(u, lane, child);
+            if (depth >= G::MAXPATH) { overflow = 1; leaf_found = true; break; }
+            if (lane == 0) path[depth] = ((uint32_t)cur << 6) | ((uint32_t)((flags >> 4) & 3) << 4) | (uint32_t)a;
+            if (child == CHILD_NONE) {
+                typename G::State st2;
+                bool terminal;
+                child = create_child<G>(d, g, pool, node, st, a, lane, nn, st2, terminal);
+                if (child == CHILD_NONE) { overflow = 1; leaf_found = true; break; }
+                st = st2;
+                flags = (terminal ? NODE_TERMINAL : 0) | (gs_player(st2) << 4);
+                have = true;
+            }
+            depth++;
+            cur = child & ~CHILD_TERM_BIT;
+        }
+        if (lane == 0) {
+            d.resume_cur[g] = parked ? cur : -1;
+            d.resume_depth[g] = parked ? depth : 0;
+        }
+        if (parked) break;
+        if (!leaf_found) {           // cached terminal: loop on to the next simulation (or the move)
+            if (lane == 0) d.sim_serial[g] += 1;
+            continue;
+        }
+        if (lane == 0) {             // post the leaf for the evaluator
+            ((typename G::State *)d.leaf_state)[g] = st;
+            d.leaf_game_id[g] = d.first_game_id + (uint32_t)d.game_lid[g];
+            d.leaf_serial[g] = cur;
+            d.pend_leaf[g] = cur;
+            d.pend_expand[g] = expand;
+            d.path_len[g] = depth;
+            d.sim_serial[g] += 1;
+            d.evals[g] += 1;
+            d.ctr[(size_t)g * 8 + 6] += (uint64_t)overflow;
+        }
+        sims_done++;
+        depth_sum += depth;
+        term_hits += term ? 1 : 0;
+        posted = true;
+        break;
+    }
+    if (lane == 0 && sims_done) {
+        uint64_t *c = d.ctr + (size_t)g * 8;
+        c[0] += (uint64_t)sims_done;
+        c[1] += (uint64_t)depth_sum;
+        c[3] += (uint64_t)term_hits;
+    }
+    return posted;
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_tree_async(TreeDev d, int round) {
+    constexpr int S = G::S;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int wv = t >> 6, l64 = t & 63;
+    int g = wv * d.gpw + l64 / S, lane = l64 % S;
+    bool live = l64 < d.gpw * S && g < d.n_slots;
+    bool posted = live ? async_game<G>(d, g, lane) : false;
+    // wave-aggregated append to the round's compacted leaf list
+    unsigned long long m = __ballot(posted && lane == 0);
+    if (t == 0) d.post_count[(round + 2) & 3] = 0; // recycled two rounds from now
+    if (m) {
+        int leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (l64 == leader) base = atomicAdd(&d.post_count[round & 3], __popcll(m));
+        base = __shfl(base, leader, 64);
+        if (posted && lane == 0) d.post_slot[base + __popcll(m & ((1ull << l64) - 1ull))] = g;
     }
 }

@@ -310,6 +310,7 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
         d.path_len[g] = depth;
         d.sims_left[g] -= 1;
         d.sim_serial[g] += 1;
+        d.evals[g] += 1;
         uint64_t *c = d.ctr + (size_t)g * 8;
         c[0] += 1;
         c[1] += (uint64_t)depth;
@@ -615,7 +616,7 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_move(TreeDev d, DCEdges E) 
         c[4] += 1;
         c[5] += 1;
         c[7] += (uint64_t)(ply + 1);
-        int next = lid + d.n_slots;
+        int next = lid + d.lid_stride;
         if (next < d.n_games_target) {
             dc_reset_slot(d, E, g, next, DragonChess::initial());
             d.sims_left[g] = d.sims_per_move;

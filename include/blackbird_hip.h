@@ -133,7 +133,7 @@ typedef struct {
 typedef struct bb_engine bb_engine;
 
 typedef struct {
-    uint64_t sims;            /* simulations run (== leaf evaluations: 1 per simulation) */
+    uint64_t sims;            /* simulations completed */
     uint64_t sum_depth;       /* sum over simulations of the leaf depth (edges) */
     uint64_t nodes;           /* tree nodes created */
     uint64_t terminal_leaves; /* simulations that ended on a terminal leaf */
@@ -141,6 +141,7 @@ typedef struct {
     uint64_t plies;           /* moves played in self-play */
     uint64_t overflow;        /* simulations cut short by pool/path limits (must be 0) */
     uint64_t examples;        /* examples stored */
+    uint64_t evals;           /* leaves evaluated (< sims when known terminal values are reused) */
 } bb_counters;
 
 int bb_create(const bb_config *cfg, bb_engine **out);
@@ -160,6 +161,9 @@ int bb_timing_read(bb_engine *e, double *mean_ms_out, double *min_ms_out, int *c
 /* Time `iters` back-to-back launches of the network kernel over the n_slots leaf mailbox (HIP events
  * on the engine stream); ablate != 0 switches parts of the kernel off (kernel tuning only). */
 int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, double *ms_per_launch_out);
+/* Which launch structure bb_selfplay_step uses: 0 lock-step (one tree + one evaluator launch per
+ * simulation), 1 asynchronous rounds, 2 persistent per-CU kernel (tree + network waves in one workgroup). */
+int bb_selfplay_mode(bb_engine *e);
 
 /* Network.getEvaluation + getPolicy for n positions (Network.py:48-64; graph NetworkFactory.py:22-183).
  * Exactly one of states (packed) / planes (int8 [n][H][W][C], what AsInputArray returns) is non-NULL.

@@ -47,11 +47,12 @@ double orc_u53(uint64_t key, uint32_t game_id, uint32_t ply) {
  * Johnk's method: X=U^(1/a), Y=V^(1/b); accept when X+Y<=1; return X/(X+Y). */
 float orc_beta_noise(uint64_t key, uint32_t game_id, uint32_t node_serial, uint32_t action, float alpha) {
     float ia = 1.0f / alpha, ib = 1.0f / (1.0f - alpha);
-    for (uint32_t trial = 0; trial < 64; trial++) {
+    for (uint32_t trial = 0; trial < 64; trial++) { /* trial t: counter sub-index t/2, words 2(t&1), 2(t&1)+1 */
         uint32_t x[4];
-        orc_philox(key, game_id, node_serial, TAG_NOISE, action * 64u + trial, x);
-        float u = ((float)(x[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        float v = ((float)(x[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        orc_philox(key, game_id, node_serial, TAG_NOISE, action * 64u + trial / 2, x);
+        uint32_t h = trial & 1u;
+        float u = ((float)(x[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        float v = ((float)(x[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
         float X = powf(u, ia), Y = powf(v, ib);
         if (X + Y <= 1.0f && X + Y > 0.0f) return X / (X + Y);
     }
