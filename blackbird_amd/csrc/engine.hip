@@ -179,6 +179,7 @@ struct bb_engine {
     TreeDev dev;
     DCEdges edges; // DragonChess only
     int32_t *d_child_action = nullptr;
+    float *d_eval_noise = nullptr;
     NetDev net;
     bool has_weights = false;
     int net_F = 0, net_C = 0;
@@ -246,7 +247,8 @@ static int engine_alloc(bb_engine *e) {
         dalloc(e, d.out_root_plays, n) || dalloc(e, d.out_child_plays, n * G::S) ||
         dalloc(e, d.out_root_winrate, n) || dalloc(e, d.out_child_value, n * G::S) || dalloc(e, e->d_u, n) ||
         dalloc(e, e->d_actions, n) || dalloc(e, d.stamps, 8) || dalloc(e, d.resume_cur, n) ||
-        dalloc(e, d.resume_depth, n) || dalloc(e, d.post_count, 8) || dalloc(e, d.post_slot, n))
+        dalloc(e, d.resume_depth, n) || dalloc(e, d.post_count, 8) || dalloc(e, d.post_slot, n) ||
+        dalloc(e, e->d_eval_noise, n * G::S))
         return BB_ERR_HIP;
     typename G::State *ls;
     if (dalloc(e, ls, n)) return BB_ERR_HIP;
@@ -344,8 +346,10 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     d.node_cap = (int)cap;
     d.example_bytes = e->info.example_bytes;
     d.gpw = 64 / e->info.S;
-    d.level_budget = 20; // measured optimum on MI355X, Connect4 @800 sims (profiles/README.md)
+    d.level_budget = 16; // measured optimum 14-20 on MI355X, Connect4 @800 sims (profiles/README.md)
     d.slot_offset = 0;
+    d.eval_noise = nullptr;
+    d.noise_alpha = cfg->alpha;
     d.lid_stride = cfg->n_slots;
     if (const char *env = getenv("BB_LEVEL_BUDGET")) {
         int v = atoi(env);
@@ -502,6 +506,7 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     nd.off_p6 = push(p6, 6);
     nd.off_pdk = push(w->p_d_k, 2 * A);
     nd.off_pdb = push(w->p_d_b, A);
+    nd.head_floats = (int)head.size();
     float *d_w0, *d_wt, *d_epi, *d_head;
     if (dalloc(e, d_w0, w0.size(), false) || dalloc(e, d_wt, wt.size(), false) || dalloc(e, d_epi, epi.size(), false) ||
         dalloc(e, d_head, head.size(), false))
@@ -849,12 +854,14 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
         return fail(BB_ERR_ARG, "asynchronous self-play is for the dense-action games");
     } else {
         constexpr int PWMAX = NetPW<G>::v;
-        if (e->mega) { // one persistent launch: `rounds` visits of every game == 2*rounds phases
+        if (e->mega && e->net.R <= MEGA_RMAX && e->net.head_floats <= MEGA_HEAD_FLOATS) { // one persistent launch: `rounds` visits of every game == 2*rounds phases
             TreeDev &d = e->dev;
             int nb = (d.n_slots + 15) / 16;
             bool timed = e->time_every > 0 && e->ev_used + 2 <= e->ev_pool.size();
             if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
-            k_selfplay_mega<G><<<nb, 512, 0, e->stream>>>(d, e->net, 2 * rounds, e->cfg.noise_on);
+            TreeDev dm = d;
+            dm.eval_noise = (e->cfg.noise_on && getenv("BB_TREE_NOISE")) ? e->d_eval_noise : nullptr; // default: network waves draw the noise
+            k_selfplay_mega<G><<<nb, MEGA_THREADS, 0, e->stream>>>(dm, e->net, 2 * rounds, e->cfg.noise_on);
             HIPCHK(hipGetLastError());
             if (timed) {
                 HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
@@ -1033,3 +1040,13 @@ extern "C" int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, dou
     return BB_OK;
 }
 
+
+#ifdef BB_STAMPS
+// diagnostic builds only (tools/): in-kernel cycle stamps accumulated by the tree / persistent kernels
+extern "C" int bb_debug_stamps(bb_engine *e, unsigned long long *out8) {
+    HIPCHK(sync_all(e));
+    HIPCHK(hipMemcpy(out8, e->dev.stamps, 64, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(e->dev.stamps, 0, 64));
+    return BB_OK;
+}
+#endif

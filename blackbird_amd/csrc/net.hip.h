@@ -31,6 +31,7 @@ struct NetDev {
     const f32x4 *wt;         // [2R][9][64]             tower convs: lane (f=l&15, j=l>>4), .r = W[tap][4j+r][f]
     const float *epi;        // [1+2R][3][16]           bias, bn scale, bn shift
     const float *head;       // packed head parameters (offsets below)
+    int head_floats;         // length of `head`
     int off_vk, off_v3, off_d1k, off_d1b, off_d2k, off_d2b, off_pk, off_p6, off_pdk, off_pdb;
     uint64_t seed;
     float alpha, eps;
@@ -60,7 +61,8 @@ template <class G, int PW>
 __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, const int *slot_list, float *wlds,
                                          const typename G::State *states, const int8_t *planes,
                                          const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
-                                         float *logits_out, float *policy_out, int pstride, bool zero_lds = true) {
+                                         float *logits_out, float *policy_out, int pstride, bool zero_lds = true,
+                                         const float *noise_in = nullptr) {
     using NG = NetGeom<G, PW>;
     constexpr int W = NG::W, CIN = NG::CIN, A = NG::A, HW = NG::HW, SLOTS = NG::SLOTS, CP = NG::CP,
                   NT = NG::NT, STEPS0 = NG::STEPS0, ACT = NG::ACT;
@@ -292,6 +294,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
             int pos = live ? OI(pos0 + q / A) : 0;
             uint32_t gid = game_id ? game_id[pos] : (uint32_t)noise, ser = serial ? (uint32_t)serial[pos] : (uint32_t)pos;
             float r = (nd.dbg & 8) ? nd.alpha : -1.0f;
+            if (noise_in && live) r = noise_in[(size_t)pos * pstride + a]; // drawn by the tree wave that posted the leaf
             for (uint32_t k = 0; k < 32 && __any(live && r < 0.0f); k += 2) {
                 float mine = (live && r < 0.0f) ? bb_beta_pair(nd.seed, gid, ser, (uint32_t)a, ia, ib, k + sub) : -1.0f;
                 float other = __shfl_xor(mine, 1, 64);

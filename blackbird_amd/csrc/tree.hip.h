@@ -103,6 +103,8 @@ struct TreeDev {
     // a TreeDev may be a VIEW of a slot range (pointers pre-offset): pipelined self-play runs two views on two streams
     int slot_offset;                    // first slot of this view in the engine
     int lid_stride;                     // engine-wide slot count: a slot's next game id is lid + lid_stride
+    float *eval_noise;                  // [n_slots][S] prior noise drawn at posting time (persistent kernel), or nullptr
+    float noise_alpha;
     unsigned long long *stamps; // diagnostic build only (BB_STAMPS): [apply, fence, select, levels, waves]
 };
 
@@ -872,6 +874,9 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
             if (lane == 0) d.sim_serial[g] += 1;
             continue;
         }
+        if (d.eval_noise && expand && lane < A) // Beta(alpha,1-alpha) prior noise for this expansion, one action per lane
+            d.eval_noise[(size_t)g * S + lane] =
+                bb_beta_noise(d.seed, d.first_game_id + (uint32_t)d.game_lid[g], (uint32_t)cur, (uint32_t)lane, d.noise_alpha);
         if (lane == 0) {             // post the leaf for the evaluator
             ((typename G::State *)d.leaf_state)[g] = st;
             d.leaf_game_id[g] = d.first_game_id + (uint32_t)d.game_lid[g];
