@@ -246,7 +246,7 @@ static int engine_alloc(bb_engine *e) {
         dalloc(e, d.eval_policy, n * PSTRIDE) || dalloc(e, d.ctr, n * 8) || dalloc(e, d.evals, n) || dalloc(e, d.out_action, n) ||
         dalloc(e, d.out_root_plays, n) || dalloc(e, d.out_child_plays, n * G::S) ||
         dalloc(e, d.out_root_winrate, n) || dalloc(e, d.out_child_value, n * G::S) || dalloc(e, e->d_u, n) ||
-        dalloc(e, e->d_actions, n) || dalloc(e, d.stamps, 8) || dalloc(e, d.resume_cur, n) ||
+        dalloc(e, e->d_actions, n) || dalloc(e, d.stamps, 16) || dalloc(e, d.resume_cur, n) ||
         dalloc(e, d.resume_depth, n) || dalloc(e, d.post_count, 8) || dalloc(e, d.post_slot, n) ||
         dalloc(e, e->d_eval_noise, n * G::S))
         return BB_ERR_HIP;
@@ -1045,8 +1045,8 @@ extern "C" int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, dou
 // diagnostic builds only (tools/): in-kernel cycle stamps accumulated by the tree / persistent kernels
 extern "C" int bb_debug_stamps(bb_engine *e, unsigned long long *out8) {
     HIPCHK(sync_all(e));
-    HIPCHK(hipMemcpy(out8, e->dev.stamps, 64, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(e->dev.stamps, 0, 64));
+    HIPCHK(hipMemcpy(out8, e->dev.stamps, 128, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(e->dev.stamps, 0, 128));
     return BB_OK;
 }
 #endif

@@ -786,21 +786,36 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
     constexpr int S = G::S, A = G::A;
     if (d.game_lid[g] < 0) return false;
     Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+#ifdef BB_STAMPS
+    long long sa0 = clock64(), s_apply = 0, s_level = 0, s_backup = 0, s_move = 0;
+#endif
     if (d.pend_leaf[g] >= 0) {
         phase_apply<G>(d, g, lane);
         if (lane == 0) d.sims_left[g] -= 1;
         __threadfence_block();
     }
+#ifdef BB_STAMPS
+    s_apply = clock64() - sa0;
+#endif
     int budget = d.level_budget;
     uint32_t *path = d.path + (size_t)g * G::MAXPATH;
     int sims_done = 0, depth_sum = 0, term_hits = 0;
     bool posted = false;
+#ifdef BB_STAMPS
+    long long st_load = 0, st_levels = 0, st_t0 = clock64();
+#endif
     for (;;) {
+#ifdef BB_STAMPS
+        long long sm0 = clock64();
+#endif
         if (d.sims_left[g] <= 0) { // MCTS.FindMove's tail, GenerateTrainingSamples' loop body
             selfplay_move_body<G>(d, g, lane);
             __threadfence_block();
             if (d.game_lid[g] < 0) break;
         }
+#ifdef BB_STAMPS
+        s_move += clock64() - sm0;
+#endif
         int cur = d.resume_cur[g], depth = 0;
         if (cur >= 0) depth = d.resume_depth[g];
         else cur = d.root[g];
@@ -811,6 +826,10 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
         for (;;) {
             if (budget <= 0) { parked = true; break; }
             budget--;
+#ifdef BB_STAMPS
+            long long ts0 = clock64();
+            st_levels++;
+#endif
             Node *node = pool + cur;
             typename G::State st_l = node->st;
             int flags_l = node->flags;
@@ -822,6 +841,9 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
             int ci = node->child[lane];
             double cached = node->pad0;
             asm volatile("" ::"v"(flags_l), "v"(mask), "v"(sq), "v"(Ni), "v"(Qi), "v"(cPi), "v"(ci));
+#ifdef BB_STAMPS
+            st_load += clock64() - ts0;
+#endif
             if (!have) {
                 st = st_l;
                 flags = flags_l;
@@ -832,6 +854,9 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
                 if (flags & NODE_TERMINAL) {
                     term = true;
                     if (flags & NODE_CACHED) { // value already known: finish this simulation here
+#ifdef BB_STAMPS
+                        long long sb0 = clock64();
+#endif
                         float v01 = (float)cached;
                         __threadfence_block(); // path stores of this descent
                         backup_path<G>(d, g, lane, pool, depth, v01, gs_prev(st));
@@ -840,6 +865,9 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
                         sims_done++;
                         depth_sum += depth;
                         term_hits++;
+#ifdef BB_STAMPS
+                        s_backup += clock64() - sb0;
+#endif
                         leaf_found = false; // nothing to post; start the next simulation
                     }
                 } else {
@@ -894,6 +922,17 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
         posted = true;
         break;
     }
+#ifdef BB_STAMPS
+    if (lane == 0 && d.stamps) {
+        atomicAdd(&d.stamps[6], (unsigned long long)st_load);
+        atomicAdd(&d.stamps[7], (unsigned long long)st_levels);
+        atomicAdd(&d.stamps[8], (unsigned long long)s_apply);
+        atomicAdd(&d.stamps[9], (unsigned long long)s_backup);
+        atomicAdd(&d.stamps[10], (unsigned long long)s_move);
+        atomicAdd(&d.stamps[11], (unsigned long long)(clock64() - st_t0));
+        atomicAdd(&d.stamps[12], 1ull);
+    }
+#endif
     if (lane == 0 && sims_done) {
         uint64_t *c = d.ctr + (size_t)g * 8;
         c[0] += (uint64_t)sims_done;
