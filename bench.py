@@ -93,8 +93,16 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        # rehearsal hooks (1-GPU box): BB_BENCH_ONE_GPU=1 maps every rank to cuda:0, BB_BENCH_BACKEND=gloo avoids RCCL's
+        # one-rank-per-device rule; the driver's real multi-GPU runs use neither
+        if os.environ.get("BB_BENCH_ONE_GPU") == "1":
+            local = 0
+        backend = os.environ.get("BB_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     game = _lib.GAME_CONNECT4
     K, Wm = args.steps, args.warmup

@@ -536,7 +536,7 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
 template <class G> struct NetPW;
 template <> struct NetPW<Connect4> { static constexpr int v = 4; };
 template <> struct NetPW<TicTacToe> { static constexpr int v = 12; };
-template <> struct NetPW<DragonChess> { static constexpr int v = 2; };
+template <> struct NetPW<DragonChess> { static constexpr int v = 1; }; // 64 pixels = 4 full tiles; 1024 games fill 256 CUs
 
 template <class G>
 static int launch_net(bb_engine *e, int n, const typename G::State *states, const int8_t *planes,

@@ -253,11 +253,17 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
             if (pos0 + pp >= n) break;
             int pos = OI(pos0 + pp);
             float *outp = policy_out ? policy_out + (size_t)pos * pstride : nullptr;
+            // sum_p (r1[p]*k1 + r0[p]*k0 + b) == k1*sum(r1) + k0*sum(r0) + HW*b: the spatial sum is taken once per
+            // position ("a global-sum-pool then a 2xA GEMV"); differs from the oracle's
+            // per-pixel order only in rounding (checked to 1e-5 in tests/test_gpu_net.py)
+            float R0 = 0.f, R1 = 0.f;
+            for (int p = 0; p < HW; p++) {
+                R0 += rp[2 * (pp * HW + p)];
+                R1 += rp[2 * (pp * HW + p) + 1];
+            }
             float m = -INFINITY;
             for (int a = lane; a < A; a += 64) {
-                float s = 0.f, k0 = pdk[a], k1 = pdk[A + a], kb = pdb[a];
-                for (int p = 0; p < HW; p++)
-                    s += __builtin_fmaf(rp[2 * (pp * HW + p) + 1], k1, __builtin_fmaf(rp[2 * (pp * HW + p)], k0, kb));
+                float s = __builtin_fmaf(R1, pdk[A + a], __builtin_fmaf(R0, pdk[a], (float)HW * pdb[a]));
                 if (logits_out) logits_out[(size_t)pos * A + a] = s;
                 if (outp) outp[a] = s;
                 m = fmaxf(m, s);
