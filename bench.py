@@ -165,9 +165,12 @@ def main():
 
     if rank == 0:
         mode = eng.selfplay_mode()
-        if mode == 2:
+        if mode >= 2:
             # persistent kernel: ONE launch covers the timed region; its FLOPs are the evaluations it performed
-            kernel, launches = "k_selfplay_mega<Connect4> (4 network + 4 tree waves per CU)", max(net_n, 1)
+            kernel = {2: "k_selfplay_mega<Connect4> (4 network + 4 tree waves per CU, lock-step phases)",
+                      3: "k_selfplay_queue<Connect4,8> (8 network + 4 tree waves per CU, LDS work queue)",
+                      4: "k_selfplay_team<Connect4,2> (2 teams of 3 network waves + 6 tree waves per CU)"}[mode]
+            launches = max(net_n, 1)
             flops_per_launch = FLOPS_PER_EVAL * cnt["evals"] / launches
         else:
             kernel = "k_net_compact<Connect4,4>" if mode == 1 else "k_net_fused16<Connect4,4>"
@@ -182,14 +185,14 @@ def main():
                                    "net R4/F16/D16 fp32, noise alpha 0.2 eps 0.3 (BASELINE configs[1])" % args.slots,
                        "game": "Connect4", "sims_per_move": args.sims, "concurrent_games_per_gpu": args.slots,
                        "blocks": 4, "filters": 16, "step": "800 tree+network rounds over all games (one ply in lock-step terms)",
-                       "launch_structure": ["lockstep", "async-rounds", "persistent"][mode],
+                       "launch_structure": ["lockstep", "async-rounds", "persistent-phases", "persistent-queue", "persistent-teams"][mode],
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
             "node_evals_per_sec": sims / dt, "net_evals_per_sec_rank0": cnt["evals"] / dt, "plies_per_sec": plies / dt,
             "games_finished": games, "terminal_leaf_fraction": cnt["terminal_leaves"] / max(cnt["sims"], 1),
             "mean_leaf_depth": cnt["sum_depth"] / max(cnt["sims"], 1), "overflow": cnt["overflow"],
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": (pmc_traffic_bytes_per_second() * net_ms * 1e-3) if (mode == 2 and pmc_traffic_bytes_per_second()) else None,
+                         "traffic": (pmc_traffic_bytes_per_second() * net_ms * 1e-3) if (mode >= 2 and pmc_traffic_bytes_per_second()) else None,
                          "traffic_note": "HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) rate from profiles/r01_v3_mega_pmc_summary.json x this launch's duration",
                          "launch_ms_mean": net_ms, "launch_ms_min": net_min_ms,
                          "launches_timed": net_n, "flops_per_launch": flops_per_launch},

@@ -8,6 +8,8 @@
 #include "tree.hip.h"
 #include "tree_dc.hip.h"
 #include "mega.hip.h"
+#include "mega2.hip.h"
+#include "mega3.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -198,6 +200,7 @@ struct bb_engine {
     hipStream_t vstream[2] = {nullptr, nullptr};
     int vround[2] = {0, 0};
     bool mega = false; // persistent per-CU self-play kernel (mega.hip.h)
+    int mega_queue = 0; // 1 work-queue kernel (mega2.hip.h), 2 work queue + network teams (mega3.hip.h)
     bool async_selfplay = false; // dense games, DynamicMCTS, deterministic evaluators: k_tree_async rounds
     int round = 0;
     int time_every = 0;
@@ -360,6 +363,8 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     if (const char *env = getenv("BB_ASYNC")) e->async_selfplay = e->async_selfplay && atoi(env) != 0;
     e->mega = e->async_selfplay && cfg->evaluator == BB_EVAL_NET;
     if (const char *env = getenv("BB_MEGA")) e->mega = e->mega && atoi(env) != 0;
+    e->mega_queue = e->mega ? 1 : 0; // default persistent kernel: the work-queue variant
+    if (const char *env = getenv("BB_MEGA_QUEUE")) e->mega_queue = e->mega ? atoi(env) : 0; // 1 work queue, 2 work queue + network teams
     if (const char *env = getenv("BB_TREE_GPW")) {
         int v = atoi(env);
         if (v >= 1 && v <= 64 / e->info.S) d.gpw = v;
@@ -432,7 +437,8 @@ extern "C" int bb_timing_read(bb_engine *e, double *mean_ms_out, double *min_ms_
 
 extern "C" int bb_selfplay_mode(bb_engine *e) {
     if (!e) return fail(BB_ERR_ARG, "null engine");
-    return e->mega ? 2 : (e->async_selfplay ? 1 : 0);
+    if (e->mega) return e->mega_queue == 2 ? 4 : (e->mega_queue == 1 ? 3 : 2);
+    return e->async_selfplay ? 1 : 0;
 }
 
 extern "C" int bb_synchronize(bb_engine *e) {
@@ -525,7 +531,7 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     nd.seed = e->cfg.seed;
     nd.alpha = e->cfg.alpha;
     nd.eps = e->cfg.epsilon;
-    nd.dbg = 0;
+    nd.dbg = getenv("BB_NET_DBG") ? atoi(getenv("BB_NET_DBG")) : 0; // ablation switches (timing experiments only; results are wrong when set)
     e->has_weights = true;
     e->net_F = F;
     e->net_C = C;
@@ -861,7 +867,29 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
             if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
             TreeDev dm = d;
             dm.eval_noise = (e->cfg.noise_on && getenv("BB_TREE_NOISE")) ? e->d_eval_noise : nullptr; // default: network waves draw the noise
-            k_selfplay_mega<G><<<nb, MEGA_THREADS, 0, e->stream>>>(dm, e->net, 2 * rounds, e->cfg.noise_on);
+            if (e->mega_queue == 2) {
+                int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
+                if constexpr (G::S == 8) {
+                    if (getenv("BB_TEAMS") && atoi(getenv("BB_TEAMS")) == 3)
+                        k_selfplay_team<G, 3><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
+                    else
+                        k_selfplay_team<G, 2><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
+                } else
+                    k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
+            } else if (e->mega_queue) {
+                int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
+                int netw = getenv("BB_QUEUE_NETW") ? atoi(getenv("BB_QUEUE_NETW")) : 8;
+                if constexpr (G::S == 8) {
+                    if (netw == 6) k_selfplay_queue<G, 6><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
+                    else if (netw == 7) k_selfplay_queue<G, 7><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
+                    else if (netw == 5) k_selfplay_queue<G, 5><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
+                    else k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
+                } else {
+                    k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
+                }
+            }
+            else
+                k_selfplay_mega<G><<<nb, MEGA_THREADS, 0, e->stream>>>(dm, e->net, 2 * rounds, e->cfg.noise_on);
             HIPCHK(hipGetLastError());
             if (timed) {
                 HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
@@ -1042,6 +1070,24 @@ extern "C" int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, dou
 
 
 #ifdef BB_STAMPS
+// diagnostic builds only: point the stamp buffer at host-coherent memory so that it can be read while a kernel runs
+extern "C" int bb_debug_host_stamps(bb_engine *e, unsigned long long **host_out) {
+    unsigned long long *p = nullptr;
+    HIPCHK(hipHostMalloc((void **)&p, 128, hipHostMallocCoherent | hipHostMallocMapped));
+    memset(p, 0, 128);
+    e->dev.stamps = p;
+    for (int v = 0; v < 2; v++) e->view[v].stamps = p;
+    *host_out = p;
+    return BB_OK;
+}
+extern "C" int bb_debug_net_stamps(bb_engine *e, unsigned long long *out8) {
+    HIPCHK(sync_all(e));
+    HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_net_stamps), 64));
+    unsigned long long z[8] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_net_stamps), z, 64));
+    return BB_OK;
+}
+extern "C" int bb_stream_done(bb_engine *e) { return hipStreamQuery(e->stream) == hipSuccess ? 1 : 0; }
 // diagnostic builds only (tools/): in-kernel cycle stamps accumulated by the tree / persistent kernels
 extern "C" int bb_debug_stamps(bb_engine *e, unsigned long long *out8) {
     HIPCHK(sync_all(e));

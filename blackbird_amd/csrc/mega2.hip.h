@@ -1,0 +1,246 @@
+// mega2.hip.h -- persistent self-play kernel with a per-CU work queue instead of lock-step phases.
+//
+// k_selfplay_mega (mega.hip.h) alternates two sets of 8 games behind one workgroup barrier per phase, so every
+// phase lasts as long as its slowest wave and two network waves on a SIMD run their MFMA and their VALU
+// sections at the same time.  Here the 16 games of a workgroup circulate freely between
+//     4 tree waves   (4 games each, S lanes per game): apply result -> [move] -> descend -> post leaf
+//     8 network waves (2 per SIMD, one position each): pop leaf -> tower + heads -> publish result
+// through an LDS ring of game indices and a per-game state word.  A network wave's head/softmax VALU work
+// overlaps its SIMD partner's MFMAs (the partners drift apart by themselves), and nobody waits for the
+// slowest game of a set.
+//
+// Synchronisation is workgroup-scope only (LDS atomics + __threadfence_block, all waves on one CU share L1),
+// so it is placement-independent.  Every wait loop is bounded by wall-clock time: a protocol bug ends the
+// launch with the abort word set (reported through the overflow counter) instead of hanging the GPU.
+#pragma once
+#include "mega.hip.h"
+
+#define MEGA2_THREADS 768 // 12 waves: NETW network waves + (12 - NETW) tree waves
+#define MEGA2_QCAP 32
+
+__device__ __forceinline__ int lds_load(volatile int *p) { return *p; }
+// Release for a flag that lives in LDS while the data lives in global memory: the workgroup-scope fence
+// the compiler emits waits for LDS traffic only, so a flag store could pass this wave's global stores.
+__device__ __forceinline__ void release_global_then_lds() {
+    __threadfence_block();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#ifdef BB_QMARK
+#define QMARK(v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && d.stamps) __hip_atomic_store(&d.stamps[threadIdx.x >> 6], (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+#else
+#define QMARK(v) do {} while (0)
+#endif
+
+struct QueueCtl {
+    int q[MEGA2_QCAP];
+    int head, tail, tree_done, abort_flag;
+};
+
+// Pop one queued game for a network wave: >= 0 game index, -1 nothing queued right now, -2 finished (or aborted).
+// Deliberately NOT inlined: with the lane-0 pop inlined into the wave's loop the compiler threads the other 63
+// lanes past it, and the wave then runs the network with lane 0 split off from the rest.
+__device__ __attribute__((noinline)) int queue_pop(QueueCtl *c, long long t_start, long long t_limit, int n_tree) {
+    int li = -1;
+    if ((threadIdx.x & 63) == 0) {
+        int h = lds_load(&c->head), t = lds_load(&c->tail);
+        if (h < t) {
+            if (atomicCAS(&c->head, h, h + 1) == h) { // compare-and-swap so that an empty queue is never over-popped
+                volatile int *slot = &c->q[h & (MEGA2_QCAP - 1)];
+                for (int spin = 0; spin < (1 << 20) && (li = *slot) < 0; spin++) __builtin_amdgcn_s_sleep(1);
+                *slot = -1; // at most 16 entries are ever outstanding, so the slot is not reused before this
+                if (li < 0) {
+                    c->abort_flag = 1;
+                    li = -2;
+                }
+            }
+        } else if (lds_load(&c->tree_done) >= n_tree) {
+            li = -2;
+        } else if (wall_clock64() - t_start > t_limit || lds_load(&c->abort_flag)) {
+            c->abort_flag = 1;
+            li = -2;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(li);
+}
+
+// Tree-wave side: publish this call's outcome for every game leader lane (`leader`) of the wave.  Not inlined for the
+// same reason as queue_pop: the lanes of the wave must come back from here together.
+__device__ __attribute__((noinline)) void queue_push(QueueCtl *c, int *state_word, bool leader, bool posted, int li) {
+    release_global_then_lds(); // mailbox + tree writes before the queue entry
+    if (leader) {
+        if (posted) {
+            *(volatile int *)state_word = 1;
+            int idx = atomicAdd(&c->tail, 1); // the entry becomes valid when its slot turns non-negative
+            *(volatile int *)&c->q[idx & (MEGA2_QCAP - 1)] = li;
+        } else {
+            *(volatile int *)state_word = 0;
+        }
+    }
+}
+
+template <class G, int NETW>
+__global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev d, NetDev nd, int visits, int noise_on, int limit_s) {
+    constexpr int S = G::S, GW = 16, TREEW = 12 - NETW, GPT = (GW + TREEW - 1) / TREEW; // games per workgroup, tree waves, games per tree wave
+    static_assert(GPT * S <= 64, "a tree wave holds at most 64 / S games");
+    using NG = NetGeom<G, 1>;
+    constexpr int RMAX = MEGA_RMAX, STEPS0 = NG::STEPS0;
+    constexpr int WT_F = 2 * RMAX * 9 * 64 * 4, W0_F = STEPS0 * 64, EPI_F = (1 + 2 * RMAX) * 48, HEAD_F = MEGA_HEAD_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[NETW * NG::WAVE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float wlds[WT_F + W0_F + EPI_F + HEAD_F];
+    __shared__ QueueCtl qc;
+    __shared__ int gstate[GW];      // 0 owned by its tree wave, 1 leaf queued / being evaluated, 2 result published
+    __shared__ int myslot[NETW];
+#ifdef BB_STAMPS
+    __shared__ long long ts_post[GW], ts_done[GW];
+#endif
+    const int wave = threadIdx.x >> 6, l64 = threadIdx.x & 63;
+    const int g0 = blockIdx.x * GW;
+    if (threadIdx.x == 0) {
+        qc.head = 0;
+        qc.tail = 0;
+        qc.tree_done = 0;
+        qc.abort_flag = 0;
+    }
+    if (threadIdx.x < GW) gstate[threadIdx.x] = 0;
+    if (threadIdx.x < MEGA2_QCAP) qc.q[threadIdx.x] = -1;
+    for (int i = threadIdx.x; i < NETW * NG::WAVE_FLOATS; i += MEGA2_THREADS) lds[i] = 0.f;
+    NetDev ndl = nd;
+    {
+        const float *gwt = (const float *)nd.wt;
+        for (int i = threadIdx.x; i < 2 * nd.R * 9 * 64 * 4; i += MEGA2_THREADS) wlds[i] = gwt[i];
+        for (int i = threadIdx.x; i < W0_F; i += MEGA2_THREADS) wlds[WT_F + i] = nd.w0[i];
+        for (int i = threadIdx.x; i < (1 + 2 * nd.R) * 48; i += MEGA2_THREADS) wlds[WT_F + W0_F + i] = nd.epi[i];
+        for (int i = threadIdx.x; i < nd.head_floats; i += MEGA2_THREADS) wlds[WT_F + W0_F + EPI_F + i] = nd.head[i];
+        ndl.wt = (const f32x4 *)wlds;
+        ndl.w0 = wlds + WT_F;
+        ndl.epi = wlds + WT_F + W0_F;
+        ndl.head = wlds + WT_F + W0_F + EPI_F;
+    }
+    __syncthreads();
+    QMARK(1);
+    const long long t_start = wall_clock64();
+    const long long t_limit = 100000000ll * limit_s; // wall clock runs at 100 MHz
+
+    if (wave >= NETW) { // ---------------- tree waves ----------------
+        const int tw = wave - NETW;
+        const int li = (l64 / S) * TREEW + tw, lane = l64 % S; // games are dealt round-robin to the tree waves
+        const bool mine = l64 < GPT * S && li < GW && g0 + li < d.n_slots;
+        const int g = g0 + li;
+        int left = mine ? visits : 0;
+#ifdef BB_STAMPS
+        long long t_work = 0, t_all0 = clock64(), n_calls = 0, n_lanes = 0, t_pick = 0, n_pick = 0;
+#endif
+        for (;;) {
+            int stt = mine ? lds_load(&gstate[li]) : 1;
+            bool ready = mine && left > 0 && stt != 1;
+            bool busy = mine && (left > 0 || stt == 1); // still owes visits, or a leaf of mine is in flight
+            if (!__any(busy)) break;
+            if (__any(ready)) {
+                __threadfence_block(); // acquire: the network wave's results for state 2
+                bool posted = false;
+                QMARK(3);
+#ifdef BB_STAMPS
+                long long ts = clock64();
+                n_calls++;
+                n_lanes += __popcll(__ballot(ready)) / S;
+                if (ready && lane == 0 && stt == 2) {
+                    t_pick += wall_clock64() - ts_done[li];
+                    n_pick++;
+                }
+#endif
+                if (ready) {
+                    posted = async_game<G>(d, g, lane);
+                    left--;
+                    if (d.game_lid[g] < 0) left = 0; // slot ran out of games
+                }
+                QMARK(4);
+#ifdef BB_STAMPS
+                if (ready && lane == 0 && posted) ts_post[li] = wall_clock64();
+#endif
+                queue_push(&qc, &gstate[li < GW ? li : 0], ready && lane == 0, posted, li);
+#ifdef BB_STAMPS
+                t_work += clock64() - ts;
+#endif
+            } else {
+                QMARK(2);
+                __builtin_amdgcn_s_sleep(4);
+                int late = wall_clock64() - t_start > t_limit || lds_load(&qc.abort_flag);
+                if (__builtin_amdgcn_readfirstlane(late)) {
+                    qc.abort_flag = 1;
+                    break;
+                }
+            }
+        }
+        QMARK(7);
+        if (l64 == 0) atomicAdd(&qc.tree_done, 1);
+#ifdef BB_STAMPS
+        if (l64 == 0 && d.stamps) {
+            atomicAdd(&d.stamps[2], (unsigned long long)t_work);
+            atomicAdd(&d.stamps[3], (unsigned long long)(clock64() - t_all0));
+            atomicAdd(&d.stamps[5], 1ull);
+            atomicAdd(&d.stamps[13], (unsigned long long)n_calls);
+            atomicAdd(&d.stamps[14], (unsigned long long)n_lanes);
+        }
+        if (lane == 0 && d.stamps && n_pick) {
+            atomicAdd(&d.stamps[8], (unsigned long long)t_pick);
+            atomicAdd(&d.stamps[9], (unsigned long long)n_pick);
+        }
+#endif
+    } else { // ---------------- network waves ----------------
+        float *wl = lds + wave * NG::WAVE_FLOATS;
+#ifdef BB_STAMPS
+        long long t_work = 0, t_all0 = clock64(), n_evals = 0, t_qwait = 0;
+#endif
+        for (;;) {
+            const int li = __builtin_amdgcn_readfirstlane(queue_pop(&qc, t_start, t_limit, TREEW)); // scalar: uniform branches below
+            if (li == -2) break;
+            if (li < 0) {
+                QMARK(20);
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+            __threadfence_block(); // acquire: the tree wave's mailbox writes
+            QMARK(5);
+#ifdef BB_STAMPS
+            long long ts = clock64();
+            n_evals++;
+            t_qwait += wall_clock64() - ts_post[li];
+#endif
+            if (l64 == 0) myslot[wave] = g0 + li;
+#ifdef Q_HASH
+            {
+                int slot = g0 + li;
+                uint64_t sl = d.salt + (d.salt_per_game ? (uint64_t)(d.leaf_game_id[slot] - d.first_game_id) : 0ull);
+                uint64_t z = hash_state<G>(((const typename G::State *)d.leaf_state)[slot], sl);
+                if (l64 == 0) d.eval_value[slot] = bb_hash_value(z);
+                if (l64 < G::A) d.eval_policy[(size_t)slot * S + l64] = bb_hash_policy(z, l64);
+            }
+#else
+            net_body<G, 1>(ndl, 1, 0, &myslot[wave], wl, (const typename G::State *)d.leaf_state, nullptr, d.leaf_game_id,
+                           d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false, nullptr);
+#endif
+            release_global_then_lds(); // value / policy before the state word
+            QMARK(6);
+#ifdef BB_STAMPS
+            if (l64 == 0) ts_done[li] = wall_clock64();
+#endif
+            if (l64 == 0) gstate[li] = 2;
+#ifdef BB_STAMPS
+            t_work += clock64() - ts;
+#endif
+        }
+#ifdef BB_STAMPS
+        if (l64 == 0 && d.stamps) {
+            atomicAdd(&d.stamps[0], (unsigned long long)t_work);
+            atomicAdd(&d.stamps[1], (unsigned long long)(clock64() - t_all0));
+            atomicAdd(&d.stamps[4], 1ull);
+            atomicAdd(&d.stamps[15], (unsigned long long)n_evals);
+            atomicAdd(&d.stamps[10], (unsigned long long)t_qwait);
+        }
+#endif
+    }
+    QMARK(8);
+    __syncthreads();
+    QMARK(9);
+    if (threadIdx.x == 0 && qc.abort_flag) d.ctr[(size_t)g0 * 8 + 6] += 1; // surfaces as bb_counters.overflow
+}

@@ -38,6 +38,16 @@ struct NetDev {
     int dbg; // ablation switches for bb_timing_net (0 in production): 1 no heads, 2 no tower, 4 no first conv
 };
 
+#ifdef BB_STAMPS
+__device__ unsigned long long g_net_stamps[8];
+#endif
+#ifdef BB_STAMPS_NET
+#define NSTAMP_ON 1 // diagnostic build: cycles per section of net_body, summed over calls
+#define NSTAMP(i) do { long long _t = clock64(); if (lane == 0) atomicAdd(&g_net_stamps[i], (unsigned long long)(_t - _ns)); _ns = clock64(); } while (0)
+#else
+#define NSTAMP(i) do {} while (0)
+#endif
+
 template <class G, int PW_>
 struct NetGeom {
     static constexpr int H = G::H, W = G::W, CIN = G::C, A = G::A;
@@ -72,6 +82,9 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
     float *actB = actA + ACT;
     float *inp = actB + ACT;
     auto OI = [&](int pos) { return slot_list ? slot_list[pos] : pos; };
+#ifdef BB_STAMPS_NET
+    long long _ns = clock64();
+#endif
 
     // ---- issue every global load of the prologue first, then zero LDS while they are in flight ---------
     // (one packed board per lane, the first conv's weights and epilogue constants)
@@ -122,6 +135,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
         aoff[t] = (pp * SLOTS + slot) * 16 + 4 * j;
         ioff[t] = (pp * SLOTS + slot) * CP;
     }
+    NSTAMP(0);
     f32x4 acc[NT];
     // ---- first conv: K = 9*CIN in natural (tap, c) order, 4 k per MFMA ---------------------------
     {
@@ -149,6 +163,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
             if (valid[t]) *(f32x4 *)(actA + aoff[t]) = y;
         }
     }
+    NSTAMP(1);
     // ---- residual tower: 2R convs, K order (tap, r, j) with channel c = 4j + r ---------------------
     const int L = (nd.dbg & 2) ? 0 : 2 * nd.R;
     for (int l = 0; l < L; l++) {
@@ -193,6 +208,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
         if (value_out && lane == 0) value_out[OI(pos0)] = acc[0][0];
         return;
     }
+    NSTAMP(2);
     // ---- heads (tower output is in actA; actB and inp are scratch now) --------------------------
     const float *hp = nd.head;
     float *rv = actB;               // [PW*HW] value-conv output
@@ -289,6 +305,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
         }
         return; // prior noise for wide games is mixed in at expansion (tree_dc.hip.h)
     }
+    NSTAMP(3);
     if constexpr (A <= 64) {
     float *nz = lg + PW * A; // [PW][A] Beta(alpha, 1-alpha) draws, one lane per (position, action)
     if (noise) { // two lanes per (position, action): lane pair (2i, 2i+1) tries Philox pairs k and k+1 side by side
@@ -310,6 +327,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
             if (live && sub == 0) nz[q] = r >= 0.0f ? r : nd.alpha;
         }
     }
+    NSTAMP(4);
     if (lane < PW && pos0 + lane < n) { // one lane finishes each position (sequential, oracle order)
         const int D = nd.D, pp = lane, pos = OI(pos0 + lane);
         const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
@@ -344,6 +362,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
             for (int a = 0; a < A; a++) policy_out[(size_t)pos * pstride + a] = pr[a];
     }
     }
+    NSTAMP(5);
     if (!zero_lds) { // persistent caller: the head scratch overlaid actB's halo slots -- restore the zeros
         const int used = 3 * PW * HW + PW * nd.D + 2 * PW * (A <= 64 ? A : 0);
         for (int i = lane; i < used; i += 64) actB[i] = 0.f;

@@ -24,6 +24,9 @@
 #ifndef BB_PREFETCH_CHILDREN
 #define BB_PREFETCH_CHILDREN 0
 #endif
+#ifndef BB_MOVE_BODY_ATTR
+#define BB_MOVE_BODY_ATTR
+#endif
 #define NODE_EXPANDED 1
 #define NODE_TERMINAL 2
 #define NODE_CACHED 4 // terminal node whose evaluator value is stored in pad0 (Model.SampleValue's lru_cache)
@@ -697,7 +700,7 @@ __device__ void write_example(const TreeDev &d, int lid, int ply, const typename
 // apply the last pending leaf, then FindMove's tail + the body of GenerateTrainingSamples' while loop
 // FindMove's tail + the body of GenerateTrainingSamples' while loop for one slot (all lanes of the group call)
 template <class G>
-__device__ void selfplay_move_body(const TreeDev &d, int g, int lane) {
+__device__ BB_MOVE_BODY_ATTR void selfplay_move_body(const TreeDev &d, int g, int lane) {
     using Node = DenseNode<G>;
     constexpr int S = G::S;
     int lid = d.game_lid[g];
@@ -786,7 +789,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
     constexpr int S = G::S, A = G::A;
     if (d.game_lid[g] < 0) return false;
     Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
-#ifdef BB_STAMPS
+#ifdef BB_STAMPS_DEEP
     long long sa0 = clock64(), s_apply = 0, s_level = 0, s_backup = 0, s_move = 0;
 #endif
     if (d.pend_leaf[g] >= 0) {
@@ -794,18 +797,18 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
         if (lane == 0) d.sims_left[g] -= 1;
         __threadfence_block();
     }
-#ifdef BB_STAMPS
+#ifdef BB_STAMPS_DEEP
     s_apply = clock64() - sa0;
 #endif
     int budget = d.level_budget;
     uint32_t *path = d.path + (size_t)g * G::MAXPATH;
     int sims_done = 0, depth_sum = 0, term_hits = 0;
     bool posted = false;
-#ifdef BB_STAMPS
+#ifdef BB_STAMPS_DEEP
     long long st_load = 0, st_levels = 0, st_t0 = clock64();
 #endif
     for (;;) {
-#ifdef BB_STAMPS
+#ifdef BB_STAMPS_DEEP
         long long sm0 = clock64();
 #endif
         if (d.sims_left[g] <= 0) { // MCTS.FindMove's tail, GenerateTrainingSamples' loop body
@@ -813,7 +816,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
             __threadfence_block();
             if (d.game_lid[g] < 0) break;
         }
-#ifdef BB_STAMPS
+#ifdef BB_STAMPS_DEEP
         s_move += clock64() - sm0;
 #endif
         int cur = d.resume_cur[g], depth = 0;
@@ -826,7 +829,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
         for (;;) {
             if (budget <= 0) { parked = true; break; }
             budget--;
-#ifdef BB_STAMPS
+#ifdef BB_STAMPS_DEEP
             long long ts0 = clock64();
             st_levels++;
 #endif
@@ -841,7 +844,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
             int ci = node->child[lane];
             double cached = node->pad0;
             asm volatile("" ::"v"(flags_l), "v"(mask), "v"(sq), "v"(Ni), "v"(Qi), "v"(cPi), "v"(ci));
-#ifdef BB_STAMPS
+#ifdef BB_STAMPS_DEEP
             st_load += clock64() - ts0;
 #endif
             if (!have) {
@@ -854,7 +857,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
                 if (flags & NODE_TERMINAL) {
                     term = true;
                     if (flags & NODE_CACHED) { // value already known: finish this simulation here
-#ifdef BB_STAMPS
+#ifdef BB_STAMPS_DEEP
                         long long sb0 = clock64();
 #endif
                         float v01 = (float)cached;
@@ -865,7 +868,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
                         sims_done++;
                         depth_sum += depth;
                         term_hits++;
-#ifdef BB_STAMPS
+#ifdef BB_STAMPS_DEEP
                         s_backup += clock64() - sb0;
 #endif
                         leaf_found = false; // nothing to post; start the next simulation
@@ -922,7 +925,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
         posted = true;
         break;
     }
-#ifdef BB_STAMPS
+#ifdef BB_STAMPS_DEEP
     if (lane == 0 && d.stamps) {
         atomicAdd(&d.stamps[6], (unsigned long long)st_load);
         atomicAdd(&d.stamps[7], (unsigned long long)st_levels);

@@ -162,7 +162,9 @@ int bb_timing_read(bb_engine *e, double *mean_ms_out, double *min_ms_out, int *c
  * on the engine stream); ablate != 0 switches parts of the kernel off (kernel tuning only). */
 int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, double *ms_per_launch_out);
 /* Which launch structure bb_selfplay_step uses: 0 lock-step (one tree + one evaluator launch per
- * simulation), 1 asynchronous rounds, 2 persistent per-CU kernel (tree + network waves in one workgroup). */
+ * simulation), 1 asynchronous rounds, 2 persistent per-CU kernel in lock-step phases (tree + network waves in
+ * one workgroup), 3 persistent per-CU kernel with a work queue between its tree and network waves (default for
+ * networks that fit LDS), 4 work queue + teams of three network waves per evaluation (experimental). */
 int bb_selfplay_mode(bb_engine *e);
 
 /* Network.getEvaluation + getPolicy for n positions (Network.py:48-64; graph NetworkFactory.py:22-183).
