@@ -31,6 +31,65 @@ __device__ __forceinline__ void release_global_then_lds() {
 #define QMARK(v) do {} while (0)
 #endif
 
+
+// ---- per-game control state shadowed in LDS for the lifetime of the launch ----------------------------------
+// async_game touches a dozen per-slot scalars, the evaluator mailbox and the recorded path of a game on every
+// call, each a dependent L2 round trip.  The persistent kernels own their 16 games for the whole launch, so they
+// copy that state into LDS once, point a private TreeDev at the copies (generic pointers, rebased so that index
+// g0 + i lands on entry i) and write everything back before the launch ends.  The node pools stay in HBM.
+// 64-bit generic (flat) address of an LDS object, as an integer the optimiser cannot trace back to LDS
+__device__ __forceinline__ unsigned long long generic_addr(const void *p) {
+    unsigned long long a = (unsigned long long)p;
+    asm volatile("" : "+v"(a));
+    return a;
+}
+
+template <class G, int GW>
+struct GameShadow {
+    static constexpr int S = G::S, MP = G::MAXPATH;
+    int32_t root[GW], root_N[GW], n_nodes[GW], ply[GW], sims_left[GW], pend_leaf[GW], pend_expand[GW], path_len[GW],
+        game_lid[GW], sim_serial[GW], leaf_serial[GW], resume_cur[GW], resume_depth[GW];
+    uint32_t leaf_game_id[GW];
+    float root_W[GW], eval_value[GW];
+    float eval_policy[GW * S];
+    uint64_t evals[GW];
+    uint64_t ctr[GW * 8];
+    typename G::State leaf_state[GW];
+    uint32_t path[GW * MP];
+    int8_t root_pp[GW];
+
+#define BB_SHADOW_ARRAYS(X)                                                                                           \
+    X(root, 1) X(root_N, 1) X(n_nodes, 1) X(ply, 1) X(sims_left, 1) X(pend_leaf, 1) X(pend_expand, 1) X(path_len, 1)  \
+    X(game_lid, 1) X(sim_serial, 1) X(leaf_serial, 1) X(resume_cur, 1) X(resume_depth, 1) X(leaf_game_id, 1)          \
+    X(root_W, 1) X(eval_value, 1) X(eval_policy, S) X(evals, 1) X(ctr, 8) X(path, MP) X(root_pp, 1)
+
+    // all threads of the workgroup; n = games of this workgroup that exist (g0 + i < n_slots)
+    __device__ __forceinline__ void load(const TreeDev &d, int g0, int n, int nthreads) {
+#define X(f, per) for (int i = threadIdx.x; i < n * (per); i += nthreads) f[i] = d.f[(size_t)g0 * (per) + i];
+        BB_SHADOW_ARRAYS(X)
+#undef X
+        for (int i = threadIdx.x; i < n; i += nthreads) leaf_state[i] = ((const typename G::State *)d.leaf_state)[g0 + i];
+    }
+    __device__ __forceinline__ void store(const TreeDev &d, int g0, int n, int nthreads, unsigned mask = ~0u) {
+        int k = 0;
+#define X(f, per) if ((mask >> k++) & 1u) for (int i = threadIdx.x; i < n * (per); i += nthreads) d.f[(size_t)g0 * (per) + i] = f[i];
+        BB_SHADOW_ARRAYS(X)
+#undef X
+        if ((mask >> k) & 1u) for (int i = threadIdx.x; i < n; i += nthreads) ((typename G::State *)d.leaf_state)[g0 + i] = leaf_state[i];
+    }
+    __device__ __forceinline__ TreeDev rebased(const TreeDev &d, int g0, unsigned mask = ~0u) {
+        TreeDev r = d;
+        int k = 0;
+        // (integer arithmetic on the generic address: `array - g0` as pointer arithmetic is out of bounds, and the
+        // compiler folds it into 32-bit LDS-offset arithmetic that wraps)
+#define X(f, per) if ((mask >> k++) & 1u) r.f = (decltype(r.f))(generic_addr(f) - (unsigned long long)g0 * (per) * sizeof(f[0]));
+        BB_SHADOW_ARRAYS(X)
+#undef X
+        if ((mask >> k) & 1u) r.leaf_state = (void *)(generic_addr(leaf_state) - (unsigned long long)g0 * sizeof(leaf_state[0]));
+        return r;
+    }
+};
+
 struct QueueCtl {
     int q[MEGA2_QCAP];
     int head, tail, tree_done, abort_flag;
@@ -79,7 +138,7 @@ __device__ __attribute__((noinline)) void queue_push(QueueCtl *c, int *state_wor
 }
 
 template <class G, int NETW>
-__global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev d, NetDev nd, int visits, int noise_on, int limit_s) {
+__global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, NetDev nd, int visits, int noise_on, int limit_s) {
     constexpr int S = G::S, GW = 16, TREEW = 12 - NETW, GPT = (GW + TREEW - 1) / TREEW; // games per workgroup, tree waves, games per tree wave
     static_assert(GPT * S <= 64, "a tree wave holds at most 64 / S games");
     using NG = NetGeom<G, 1>;
@@ -88,6 +147,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev d, Net
     __shared__ __attribute__((aligned(16))) float lds[NETW * NG::WAVE_FLOATS];
     __shared__ __attribute__((aligned(16))) float wlds[WT_F + W0_F + EPI_F + HEAD_F];
     __shared__ QueueCtl qc;
+    __shared__ GameShadow<G, GW> shadow;
     __shared__ int gstate[GW];      // 0 owned by its tree wave, 1 leaf queued / being evaluated, 2 result published
     __shared__ int myslot[NETW];
 #ifdef BB_STAMPS
@@ -95,6 +155,11 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev d, Net
 #endif
     const int wave = threadIdx.x >> 6, l64 = threadIdx.x & 63;
     const int g0 = blockIdx.x * GW;
+    const int n_mine = dg.n_slots - g0 < GW ? dg.n_slots - g0 : GW;
+    shadow.load(dg, g0, n_mine, MEGA2_THREADS);
+    const unsigned smask = (unsigned)limit_s >> 8;
+    const TreeDev d = shadow.rebased(dg, g0, smask); // everything below works on the LDS copies
+    limit_s &= 255;
     if (threadIdx.x == 0) {
         qc.head = 0;
         qc.tail = 0;
@@ -123,6 +188,9 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev d, Net
 
     if (wave >= NETW) { // ---------------- tree waves ----------------
         const int tw = wave - NETW;
+        // the tree waves are the latency chain of every game: let them win issue arbitration against the
+        // throughput-bound network waves of their SIMD (+8 % games/s)
+        __builtin_amdgcn_s_setprio(3);
         const int li = (l64 / S) * TREEW + tw, lane = l64 % S; // games are dealt round-robin to the tree waves
         const bool mine = l64 < GPT * S && li < GW && g0 + li < d.n_slots;
         const int g = g0 + li;
@@ -243,4 +311,6 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev d, Net
     __syncthreads();
     QMARK(9);
     if (threadIdx.x == 0 && qc.abort_flag) d.ctr[(size_t)g0 * 8 + 6] += 1; // surfaces as bb_counters.overflow
+    __syncthreads();
+    shadow.store(dg, g0, n_mine, MEGA2_THREADS, smask); // hand the per-game state back to HBM
 }

@@ -175,11 +175,22 @@ __device__ __forceinline__ void argmax_step(double &u, int &idx, int &payload) {
 }
 template <int S>
 __device__ __forceinline__ int grp_argmax(double u, int idx, int &payload) {
-    argmax_step<S, 0>(u, idx, payload);
-    argmax_step<S, 1>(u, idx, payload);
-    argmax_step<S, 2>(u, idx, payload);
-    if (S == 16) argmax_step<S, 3>(u, idx, payload);
-    return idx;
+    // Two stages instead of a compare-and-select butterfly (whose value/index/payload selects compile to a chain of
+    // VALU->SALU exec-mask round trips): the group maximum by v_max_f64 butterflies, then the first lane that holds
+    // it (np.argmax: first maximum wins) from one wave-wide equality ballot, then one cross-lane read of the payload.
+    // Legal scores are >= -1 and never NaN (illegal lanes are exactly -1.0), so max/== see ordinary numbers.
+    (void)idx;
+    double m = u;
+    m = __builtin_fmax(m, dpp_step_d<0>(m));
+    m = __builtin_fmax(m, dpp_step_d<1>(m));
+    m = __builtin_fmax(m, dpp_step_d<2>(m));
+    if (S == 16) m = __builtin_fmax(m, dpp_step_d<3>(m));
+    const unsigned long long eq = __ballot(u == m);
+    const int l64 = (int)__lane_id();
+    const unsigned grp = (unsigned)(eq >> (l64 & ~(S - 1))) & ((1u << S) - 1u);
+    const int win = __ffs(grp) - 1;
+    payload = __shfl(payload, win, S);
+    return win;
 }
 
 // U_i = ChildWinRates_i + (ExplorationRate * Priors_i * sqrt(1 + allPlays)) / (1 + ChildPlays_i)   (MCTS.py:327-332)

@@ -21,6 +21,9 @@ st = st.astype(np.float64)
 print(f"3 plies in {dt*1e3:.1f} ms")
 print(f"pairs {st[11]:.0f}"); print(f"net waves: busy {st[0]/st[1]:.3f}; cycles per evaluation {st[0]/st[15]:.0f}; evaluations {st[15]:.0f}")
 print(f"tree waves: busy {st[2]/st[3]:.3f}; cycles per async call {st[2]/st[13]:.0f}; games per call {st[14]/st[13]:.2f}; calls {st[13]:.0f}")
+v = st[12]
+if v > 0 and os.environ.get("QMODE", "1") == "1":
+    print(f"DEEP per game-visit cycles: total {st[11]/v:.0f} apply {st[8]/v:.0f} cached-backups {st[9]/v:.0f} move {st[10]/v:.0f} load-wait {st[6]/v:.0f}; levels/visit {st[7]/v:.2f}")
 clk = 2.4e3  # shader cycles per us (approx); wall clock ticks are 100 MHz
 print(f"per evaluation: queue wait {st[10]/st[15]/100:.1f} us, network {st[0]/st[15]/clk:.1f} us; result pick-up wait {st[8]/max(st[9],1)/100:.1f} us; tree call {st[2]/st[13]/clk:.1f} us")
 L.bb_debug_net_stamps(eng.h, ns.ctypes.data); ns = ns.astype(np.float64)
