@@ -870,11 +870,6 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
             if (e->mega_queue == 2) {
                 int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
                 if constexpr (G::S == 8) {
-#ifndef BB_STAMPS // (the diagnostic build's stamp arrays do not fit next to three teams' LDS)
-                    if (getenv("BB_TEAMS") && atoi(getenv("BB_TEAMS")) == 3)
-                        k_selfplay_team<G, 3><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
-                    else
-#endif
                         k_selfplay_team<G, 2><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
                 } else
                     k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);

@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
             }
 #else
             net_body<G, 1>(ndl, 1, 0, &myslot[wave], wl, (const typename G::State *)d.leaf_state, nullptr, d.leaf_game_id,
-                           d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false, nullptr);
+                           d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false, d.eval_noise);
 #endif
             release_global_then_lds(); // value / policy before the state word
             QMARK(6);

@@ -71,7 +71,7 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
     static_assert(T == 3, "head roles are written for teams of three waves");
     using NG = NetGeom<G, PW>;
     constexpr int W = NG::W, CIN = NG::CIN, A = NG::A, HW = NG::HW, SLOTS = NG::SLOTS, CP = NG::CP, NT = NG::NT,
-                  STEPS0 = NG::STEPS0, ACT = NG::ACT;
+                  STEPS0 = NG::STEPS0, ACT = NG::ACT, PLANE = NG::PLANE;
     constexpr int NTW = (NT + T - 1) / T; // tiles per wave
     const int lane = threadIdx.x & 63;
     const int j = lane >> 4, nn = lane & 15;
@@ -107,7 +107,7 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
         int qq = valid[k] ? q : 0;
         int pp = qq / HW, cell = qq % HW, y = cell / W, x = cell % W;
         int slot = valid[k] ? (y + 1) * (W + 1) + (x + 1) : 0; // invalid lanes read the (zero) corner halo
-        aoff[k] = (pp * SLOTS + slot) * 16 + 4 * j;
+        aoff[k] = j * PLANE + (pp * SLOTS + slot) * 4;
         ioff[k] = (pp * SLOTS + slot) * CP;
     }
     TSTAMP(0);
@@ -156,7 +156,7 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
         for (int k = 0; k < NTW; k++) acc[k] = bias;
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
-            const int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * 16;
+            const int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * 4;
             f32x4 b[NTW];
 #pragma unroll
             for (int k = 0; k < NTW; k++) b[k] = *(const f32x4 *)(in + aoff[k] + toff);
@@ -196,11 +196,11 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
         const float *vk = hp + nd.off_vk, *v3 = hp + nd.off_v3;
         for (int q = lane; q < PW * HW; q += 64) {
             int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
-            const float *xp = actA + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * 16;
+            const float *xp = actA + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * 4;
             float av = v3[0];
 #pragma unroll
             for (int c4 = 0; c4 < 4; c4++) {
-                f32x4 xv = *(const f32x4 *)(xp + 4 * c4);
+                f32x4 xv = *(const f32x4 *)(xp + c4 * PLANE);
 #pragma unroll
                 for (int r = 0; r < 4; r++) av = __builtin_fmaf(xv[r], vk[4 * c4 + r], av);
             }
@@ -226,11 +226,11 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
         const float *pk = hp + nd.off_pk, *p6 = hp + nd.off_p6;
         for (int q = lane; q < PW * HW; q += 64) {
             int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
-            const float *xp = actA + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * 16;
+            const float *xp = actA + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * 4;
             float a0 = p6[0], a1 = p6[1];
 #pragma unroll
             for (int c4 = 0; c4 < 4; c4++) {
-                f32x4 xv = *(const f32x4 *)(xp + 4 * c4);
+                f32x4 xv = *(const f32x4 *)(xp + c4 * PLANE);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     int c = 4 * c4 + r;
@@ -317,7 +317,7 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
 #endif
 
 template <class G, int NTEAMS>
-__global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev d, NetDev nd, int visits, int noise_on, int limit_s) {
+__global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev dg, NetDev nd, int visits, int noise_on, int limit_s) {
     constexpr int S = G::S, GW = 16, T = 3, NETW = NTEAMS * T, TREEW = 12 - NETW, GPT = (GW + TREEW - 1) / TREEW, PWT = 2;
     static_assert(GPT * S <= 64, "a tree wave holds at most 64 / S games");
     using NG = NetGeom<G, PWT>;
@@ -329,6 +329,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev d, NetD
     __shared__ __attribute__((aligned(16))) float lds1[NTEAMS * NG1::WAVE_FLOATS];
     __shared__ __attribute__((aligned(16))) float wlds[WT_F + W0_F + EPI_F + HEAD_F];
     __shared__ QueueCtl qc;
+    __shared__ GameShadow<G, GW> shadow;
     __shared__ TeamCtl tcs[NTEAMS];
     __shared__ int gstate[GW]; // 0 owned by its tree wave, 1 leaf queued / being evaluated, 2 result published
 #ifdef BB_STAMPS
@@ -338,6 +339,9 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev d, NetD
 #endif
     const int wave = threadIdx.x >> 6, l64 = threadIdx.x & 63;
     const int g0 = blockIdx.x * GW;
+    const int n_mine = dg.n_slots - g0 < GW ? dg.n_slots - g0 : GW;
+    shadow.load(dg, g0, n_mine, MEGA2_THREADS);
+    const TreeDev d = shadow.rebased(dg, g0); // everything below works on the LDS copies
     if (threadIdx.x == 0) {
         qc.head = 0;
         qc.tail = 0;
@@ -367,6 +371,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev d, NetD
 
     if (wave >= NETW) { // ---------------- tree waves ----------------
         const int tw = wave - NETW;
+        __builtin_amdgcn_s_setprio(3); // the tree waves are the latency chain of every game
         const int li = (l64 / S) * TREEW + tw, lane = l64 % S; // games are dealt round-robin to the tree waves
         const bool mine = l64 < GPT * S && li < GW && g0 + li < d.n_slots;
         const int g = g0 + li;
@@ -512,4 +517,6 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev d, NetD
 #endif
     __syncthreads();
     if (threadIdx.x == 0 && qc.abort_flag) d.ctr[(size_t)g0 * 8 + 6] += 1; // surfaces as bb_counters.overflow
+    __syncthreads();
+    shadow.store(dg, g0, n_mine, MEGA2_THREADS); // hand the per-game state back to HBM
 }

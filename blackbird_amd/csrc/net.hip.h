@@ -58,185 +58,28 @@ struct NetGeom {
     static constexpr int NT = (PW * HW + 15) / 16;     // 16-pixel tiles per wave
     static constexpr int STEPS0 = (9 * CIN + 3) / 4;   // MFMA k-steps of the first conv
     static constexpr int ACT = PW * SLOTS * 16;        // floats per activation buffer
+    static constexpr int PLANE = PW * SLOTS * 4;       // an activation buffer is [4 channel groups][PW][SLOTS][4 channels]:
+                                                       // the 16 pixels of a tile x 16 B are contiguous -> conflict-free ds_read_b128
     static constexpr int STATE_FLOATS = (PW * (int)sizeof(typename G::State) + 15) / 16 * 4; // packed boards staged in LDS
     static constexpr int WAVE_FLOATS = 2 * ACT + PW * SLOTS * CP + STATE_FLOATS;
     static constexpr int LDS_BYTES = 4 * WAVE_FLOATS * 4;
     static_assert(LDS_BYTES <= 163840, "activations must fit the 160 KiB LDS");
 };
 
-// The whole network for the PW positions [pos0, pos0+PW) of a batch of n, computed by ONE wave in its
-// own LDS region `wlds` (NetGeom<G,PW>::WAVE_FLOATS floats).  slot_list != nullptr: batch entry i is
-// engine slot slot_list[i] (inputs are read from, and outputs written to, that slot's mailbox).
+// Everything after the two 1x1 head convolutions, shared by the fused F=16 kernels and the general-F path
+// (gnet.hip.h): rv / rp hold relu(bn(conv)) per pixel of the PW positions, sd / lg are scratch.
+// NetworkFactory.py:100-183: dense_1 per pixel -> reduce_sum -> ReLU -> dense_2 -> tanh;  policy dense on the
+// last axis -> reduce_sum -> softmax (-> Dirichlet mix).
 template <class G, int PW>
-__device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, const int *slot_list, float *wlds,
-                                         const typename G::State *states, const int8_t *planes,
-                                         const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
-                                         float *logits_out, float *policy_out, int pstride, bool zero_lds = true,
-                                         const float *noise_in = nullptr) {
+__device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0, const int *slot_list, const float *rv,
+                                              const float *rp, float *sd, float *lg, const uint32_t *game_id,
+                                              const int32_t *serial, int noise, float *value_out, float *logits_out,
+                                              float *policy_out, int pstride, const float *noise_in) {
     using NG = NetGeom<G, PW>;
-    constexpr int W = NG::W, CIN = NG::CIN, A = NG::A, HW = NG::HW, SLOTS = NG::SLOTS, CP = NG::CP,
-                  NT = NG::NT, STEPS0 = NG::STEPS0, ACT = NG::ACT;
+    constexpr int A = NG::A, HW = NG::HW;
     const int lane = threadIdx.x & 63;
-    const int j = lane >> 4, nn = lane & 15;
-    float *actA = wlds;
-    float *actB = actA + ACT;
-    float *inp = actB + ACT;
-    auto OI = [&](int pos) { return slot_list ? slot_list[pos] : pos; };
-#ifdef BB_STAMPS_NET
-    long long _ns = clock64();
-#endif
-
-    // ---- issue every global load of the prologue first, then zero LDS while they are in flight ---------
-    // (one packed board per lane, the first conv's weights and epilogue constants)
-    const int my_pp = lane % PW;
-    const typename G::State my_state = planes ? G::initial() : states[OI(pos0 + my_pp < n ? pos0 + my_pp : pos0)];
-    float w0r[STEPS0];
-#pragma unroll
-    for (int s = 0; s < STEPS0; s++) w0r[s] = nd.w0[s * 64 + lane];
-    const f32x4 bias0 = *(const f32x4 *)(nd.epi + 4 * j), scale0 = *(const f32x4 *)(nd.epi + 16 + 4 * j),
-                shift0 = *(const f32x4 *)(nd.epi + 32 + 4 * j);
-    // ---- zero this wave's LDS (halo pixels must read as 0 forever) --------------------------
-    if (zero_lds) { // a persistent caller zeroes once: halos are never written, interiors are always rewritten
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        f32x4 *p = (f32x4 *)actA;
-        for (int i = lane; i < NG::WAVE_FLOATS / 4; i += 64) p[i] = z;
-    }
-    // the PW boards go through LDS so that every lane can decode any cell of any position
-    typename G::State *sst = (typename G::State *)(inp + PW * SLOTS * CP);
-    if (!planes && lane < PW) sst[lane] = my_state;
-    // ---- input planes -> inp[pos][slot][CP] ---------------------------------------------------
-    for (int q = lane; q < PW * HW; q += 64) {
-        int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
-        int pos = pos0 + pp;
-        if (pos >= n) continue;
-        float *dst = inp + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * CP;
-        if (planes) {
-            const int8_t *src = planes + ((size_t)pos * HW + cell) * CIN;
-#pragma unroll
-            for (int c = 0; c < CIN; c++) dst[c] = (float)src[c];
-        } else {
-            int8_t v[CIN];
-            G::encode_cell(sst[pp], y, x, v);
-#pragma unroll
-            for (int c = 0; c < CIN; c++) dst[c] = (float)v[c];
-        }
-    }
-    // ---- per-tile addressing: lane (j, nn) <-> pixel nn of the tile, channels 4j..4j+3 ---------
-    int aoff[NT];   // float offset of (pos, slot, channel 4j) inside an activation buffer
-    int ioff[NT];   // float offset of (pos, slot) inside inp
-    bool valid[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        int q = t * 16 + nn;
-        valid[t] = q < PW * HW;
-        int qq = valid[t] ? q : 0;
-        int pp = qq / HW, cell = qq % HW, y = cell / W, x = cell % W;
-        int slot = valid[t] ? (y + 1) * (W + 1) + (x + 1) : 0; // invalid lanes read the (zero) corner halo
-        aoff[t] = (pp * SLOTS + slot) * 16 + 4 * j;
-        ioff[t] = (pp * SLOTS + slot) * CP;
-    }
-    NSTAMP(0);
-    f32x4 acc[NT];
-    // ---- first conv: K = 9*CIN in natural (tap, c) order, 4 k per MFMA ---------------------------
-    {
-        const f32x4 bias = bias0, scale = scale0, shift = shift0;
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = bias;
-#pragma unroll
-        for (int s = 0; s < STEPS0; s++) {
-            int k = 4 * s + j;
-            int kk = k < 9 * CIN ? k : 9 * CIN - 1; // padded k: weight is 0, any readable address will do
-            int tap = kk / CIN, c = kk % CIN;
-            int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * CP + c;
-            float a = w0r[s];
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                float b = inp[ioff[t] + toff];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            f32x4 y;
-#pragma unroll
-            for (int r = 0; r < 4; r++) y[r] = fmaxf(__builtin_fmaf(acc[t][r], scale[r], shift[r]), 0.f);
-            if (valid[t]) *(f32x4 *)(actA + aoff[t]) = y;
-        }
-    }
-    NSTAMP(1);
-    // ---- residual tower: 2R convs, K order (tap, r, j) with channel c = 4j + r ---------------------
-    const int L = (nd.dbg & 2) ? 0 : 2 * nd.R;
-    for (int l = 0; l < L; l++) {
-        const float *in = (l & 1) ? actB : actA;
-        float *out = (l & 1) ? actA : actB;
-        const float *ep = nd.epi + (size_t)(1 + l) * 48;
-        f32x4 bias = *(const f32x4 *)(ep + 4 * j), scale = *(const f32x4 *)(ep + 16 + 4 * j),
-              shift = *(const f32x4 *)(ep + 32 + 4 * j);
-        f32x4 w[9];
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) w[tap] = nd.wt[((size_t)l * 9 + tap) * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = bias;
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * 16;
-            f32x4 b[NT];
-#pragma unroll
-            for (int t = 0; t < NT; t++) b[t] = *(const f32x4 *)(in + aoff[t] + toff);
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-#pragma unroll
-                for (int t = 0; t < NT; t++)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][r], b[t][r], acc[t], 0, 0, 0);
-        }
-        const bool skip = (l & 1) != 0; // tf.add(batch_norm_2, block input) before the ReLU
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            f32x4 y;
-            f32x4 sk = {0.f, 0.f, 0.f, 0.f};
-            if (skip) sk = *(const f32x4 *)(out + aoff[t]);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = __builtin_fmaf(acc[t][r], scale[r], shift[r]);
-                if (skip) v = v + sk[r];
-                y[r] = fmaxf(v, 0.f);
-            }
-            if (valid[t]) *(f32x4 *)(out + aoff[t]) = y;
-        }
-    }
-    if (nd.dbg & 1) {
-        if (value_out && lane == 0) value_out[OI(pos0)] = acc[0][0];
-        return;
-    }
-    NSTAMP(2);
-    // ---- heads (tower output is in actA; actB and inp are scratch now) --------------------------
     const float *hp = nd.head;
-    float *rv = actB;               // [PW*HW] value-conv output
-    float *rp = actB + PW * HW;     // [PW*HW][2] policy-conv output
-    float *sd = rp + 2 * PW * HW;   // [PW][D]
-    float *lg = sd + PW * nd.D;     // [PW][A]
-    {
-        const float *vk = hp + nd.off_vk, *v3 = hp + nd.off_v3, *pk = hp + nd.off_pk, *p6 = hp + nd.off_p6;
-        for (int q = lane; q < PW * HW; q += 64) {
-            int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
-            const float *xp = actA + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * 16;
-            float av = v3[0], a0 = p6[0], a1 = p6[1];
-#pragma unroll
-            for (int c4 = 0; c4 < 4; c4++) {
-                f32x4 xv = *(const f32x4 *)(xp + 4 * c4);
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    int c = 4 * c4 + r;
-                    av = __builtin_fmaf(xv[r], vk[c], av);
-                    a0 = __builtin_fmaf(xv[r], pk[2 * c], a0);
-                    a1 = __builtin_fmaf(xv[r], pk[2 * c + 1], a1);
-                }
-            }
-            rv[q] = fmaxf(__builtin_fmaf(av, v3[1], v3[2]), 0.f);
-            rp[2 * q] = fmaxf(__builtin_fmaf(a0, p6[2], p6[4]), 0.f);
-            rp[2 * q + 1] = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
-        }
-    }
+    auto OI = [&](int pos) { return slot_list ? slot_list[pos] : pos; };
     {
         const int D = nd.D;
         const float *d1k = hp + nd.off_d1k, *d1b = hp + nd.off_d1b;
@@ -305,7 +148,6 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
         }
         return; // prior noise for wide games is mixed in at expansion (tree_dc.hip.h)
     }
-    NSTAMP(3);
     if constexpr (A <= 64) {
     float *nz = lg + PW * A; // [PW][A] Beta(alpha, 1-alpha) draws, one lane per (position, action)
     if (noise) { // two lanes per (position, action): lane pair (2i, 2i+1) tries Philox pairs k and k+1 side by side
@@ -327,7 +169,6 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
             if (live && sub == 0) nz[q] = r >= 0.0f ? r : nd.alpha;
         }
     }
-    NSTAMP(4);
     if (lane < PW && pos0 + lane < n) { // one lane finishes each position (sequential, oracle order)
         const int D = nd.D, pp = lane, pos = OI(pos0 + lane);
         const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
@@ -362,6 +203,184 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
             for (int a = 0; a < A; a++) policy_out[(size_t)pos * pstride + a] = pr[a];
     }
     }
+}
+
+// The whole network for the PW positions [pos0, pos0+PW) of a batch of n, computed by ONE wave in its
+// own LDS region `wlds` (NetGeom<G,PW>::WAVE_FLOATS floats).  slot_list != nullptr: batch entry i is
+// engine slot slot_list[i] (inputs are read from, and outputs written to, that slot's mailbox).
+template <class G, int PW>
+__device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, const int *slot_list, float *wlds,
+                                         const typename G::State *states, const int8_t *planes,
+                                         const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
+                                         float *logits_out, float *policy_out, int pstride, bool zero_lds = true,
+                                         const float *noise_in = nullptr) {
+    using NG = NetGeom<G, PW>;
+    constexpr int W = NG::W, CIN = NG::CIN, A = NG::A, HW = NG::HW, SLOTS = NG::SLOTS, CP = NG::CP,
+                  NT = NG::NT, STEPS0 = NG::STEPS0, ACT = NG::ACT, PLANE = NG::PLANE;
+    const int lane = threadIdx.x & 63;
+    const int j = lane >> 4, nn = lane & 15;
+    float *actA = wlds;
+    float *actB = actA + ACT;
+    float *inp = actB + ACT;
+    auto OI = [&](int pos) { return slot_list ? slot_list[pos] : pos; };
+#ifdef BB_STAMPS_NET
+    long long _ns = clock64();
+#endif
+
+    // ---- issue every global load of the prologue first, then zero LDS while they are in flight ---------
+    // (one packed board per lane, the first conv's weights and epilogue constants)
+    const int my_pp = lane % PW;
+    const typename G::State my_state = planes ? G::initial() : states[OI(pos0 + my_pp < n ? pos0 + my_pp : pos0)];
+    float w0r[STEPS0];
+#pragma unroll
+    for (int s = 0; s < STEPS0; s++) w0r[s] = nd.w0[s * 64 + lane];
+    const f32x4 bias0 = *(const f32x4 *)(nd.epi + 4 * j), scale0 = *(const f32x4 *)(nd.epi + 16 + 4 * j),
+                shift0 = *(const f32x4 *)(nd.epi + 32 + 4 * j);
+    // ---- zero this wave's LDS (halo pixels must read as 0 forever) --------------------------
+    if (zero_lds) { // a persistent caller zeroes once: halos are never written, interiors are always rewritten
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 *p = (f32x4 *)actA;
+        for (int i = lane; i < NG::WAVE_FLOATS / 4; i += 64) p[i] = z;
+    }
+    // the PW boards go through LDS so that every lane can decode any cell of any position
+    typename G::State *sst = (typename G::State *)(inp + PW * SLOTS * CP);
+    if (!planes && lane < PW) sst[lane] = my_state;
+    // ---- input planes -> inp[pos][slot][CP] ---------------------------------------------------
+    for (int q = lane; q < PW * HW; q += 64) {
+        int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
+        int pos = pos0 + pp;
+        if (pos >= n) continue;
+        float *dst = inp + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * CP;
+        if (planes) {
+            const int8_t *src = planes + ((size_t)pos * HW + cell) * CIN;
+#pragma unroll
+            for (int c = 0; c < CIN; c++) dst[c] = (float)src[c];
+        } else {
+            int8_t v[CIN];
+            G::encode_cell(sst[pp], y, x, v);
+#pragma unroll
+            for (int c = 0; c < CIN; c++) dst[c] = (float)v[c];
+        }
+    }
+    // ---- per-tile addressing: lane (j, nn) <-> pixel nn of the tile, channels 4j..4j+3 ---------
+    int aoff[NT];   // float offset of (channel group j, pos, slot) inside an activation buffer
+    int ioff[NT];   // float offset of (pos, slot) inside inp
+    bool valid[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        int q = t * 16 + nn;
+        valid[t] = q < PW * HW;
+        int qq = valid[t] ? q : 0;
+        int pp = qq / HW, cell = qq % HW, y = cell / W, x = cell % W;
+        int slot = valid[t] ? (y + 1) * (W + 1) + (x + 1) : 0; // invalid lanes read the (zero) corner halo
+        aoff[t] = j * PLANE + (pp * SLOTS + slot) * 4;
+        ioff[t] = (pp * SLOTS + slot) * CP;
+    }
+    NSTAMP(0);
+    f32x4 acc[NT];
+    // ---- first conv: K = 9*CIN in natural (tap, c) order, 4 k per MFMA ---------------------------
+    {
+        const f32x4 bias = bias0, scale = scale0, shift = shift0;
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = bias;
+#pragma unroll
+        for (int s = 0; s < STEPS0; s++) {
+            int k = 4 * s + j;
+            int kk = k < 9 * CIN ? k : 9 * CIN - 1; // padded k: weight is 0, any readable address will do
+            int tap = kk / CIN, c = kk % CIN;
+            int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * CP + c;
+            float a = w0r[s];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                float b = inp[ioff[t] + toff];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; r++) y[r] = fmaxf(__builtin_fmaf(acc[t][r], scale[r], shift[r]), 0.f);
+            if (valid[t]) *(f32x4 *)(actA + aoff[t]) = y;
+        }
+    }
+    NSTAMP(1);
+    // ---- residual tower: 2R convs, K order (tap, r, j) with channel c = 4j + r ---------------------
+    const int L = (nd.dbg & 2) ? 0 : 2 * nd.R;
+    for (int l = 0; l < L; l++) {
+        const float *in = (l & 1) ? actB : actA;
+        float *out = (l & 1) ? actA : actB;
+        const float *ep = nd.epi + (size_t)(1 + l) * 48;
+        f32x4 bias = *(const f32x4 *)(ep + 4 * j), scale = *(const f32x4 *)(ep + 16 + 4 * j),
+              shift = *(const f32x4 *)(ep + 32 + 4 * j);
+        f32x4 w[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) w[tap] = nd.wt[((size_t)l * 9 + tap) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = bias;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * 4;
+            f32x4 b[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) b[t] = *(const f32x4 *)(in + aoff[t] + toff);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][r], b[t][r], acc[t], 0, 0, 0);
+        }
+        const bool skip = (l & 1) != 0; // tf.add(batch_norm_2, block input) before the ReLU
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            f32x4 y;
+            f32x4 sk = {0.f, 0.f, 0.f, 0.f};
+            if (skip) sk = *(const f32x4 *)(out + aoff[t]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = __builtin_fmaf(acc[t][r], scale[r], shift[r]);
+                if (skip) v = v + sk[r];
+                y[r] = fmaxf(v, 0.f);
+            }
+            if (valid[t]) *(f32x4 *)(out + aoff[t]) = y;
+        }
+    }
+    if (nd.dbg & 1) {
+        if (value_out && lane == 0) value_out[OI(pos0)] = acc[0][0];
+        return;
+    }
+    NSTAMP(2);
+    // ---- heads (tower output is in actA; actB and inp are scratch now) --------------------------
+    const float *hp = nd.head;
+    float *rv = actB;               // [PW*HW] value-conv output
+    float *rp = actB + PW * HW;     // [PW*HW][2] policy-conv output
+    float *sd = rp + 2 * PW * HW;   // [PW][D]
+    float *lg = sd + PW * nd.D;     // [PW][A]
+    {
+        const float *vk = hp + nd.off_vk, *v3 = hp + nd.off_v3, *pk = hp + nd.off_pk, *p6 = hp + nd.off_p6;
+        for (int q = lane; q < PW * HW; q += 64) {
+            int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
+            const float *xp = actA + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * 4;
+            float av = v3[0], a0 = p6[0], a1 = p6[1];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++) {
+                f32x4 xv = *(const f32x4 *)(xp + c4 * PLANE);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int c = 4 * c4 + r;
+                    av = __builtin_fmaf(xv[r], vk[c], av);
+                    a0 = __builtin_fmaf(xv[r], pk[2 * c], a0);
+                    a1 = __builtin_fmaf(xv[r], pk[2 * c + 1], a1);
+                }
+            }
+            rv[q] = fmaxf(__builtin_fmaf(av, v3[1], v3[2]), 0.f);
+            rp[2 * q] = fmaxf(__builtin_fmaf(a0, p6[2], p6[4]), 0.f);
+            rp[2 * q + 1] = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
+        }
+    }
+    net_head_tail<G, PW>(nd, n, pos0, slot_list, rv, rp, sd, lg, game_id, serial, noise, value_out, logits_out, policy_out,
+                         pstride, noise_in);
+    if constexpr (A > 64) return; // (wide games never ran the scratch restore below)
     NSTAMP(5);
     if (!zero_lds) { // persistent caller: the head scratch overlaid actB's halo slots -- restore the zeros
         const int used = 3 * PW * HW + PW * nd.D + 2 * PW * (A <= 64 ? A : 0);
