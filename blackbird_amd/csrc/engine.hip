@@ -5,6 +5,7 @@
 #include "../../include/blackbird_hip.h"
 #include "eval.hip.h"
 #include "net.hip.h"
+#include "gnet.hip.h"
 #include "tree.hip.h"
 #include "tree_dc.hip.h"
 #include "mega.hip.h"
@@ -185,6 +186,8 @@ struct bb_engine {
     NetDev net;
     bool has_weights = false;
     int net_F = 0, net_C = 0;
+    bool general_net = false; // F != 16 (or BB_GNET=1): one implicit-GEMM launch per conv layer (gnet.hip.h)
+    GNetDev gnet = {};
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
     int n_games_target = 0;
@@ -459,23 +462,117 @@ static void bn_fold(const float *bn, int F, float *scale, float *shift) {
     }
 }
 
+
+// ---- general-F network (gnet.hip.h): operand layouts, buffers, launch sequence -----------------------------------
+template <class G>
+static int gnet_reserve(bb_engine *e, int n) {
+    using GG = GNetGeom<G>;
+    GNetDev &g = e->gnet;
+    int cap = (n + GG::PPB - 1) / GG::PPB * GG::PPB;
+    if (cap <= g.cap) return BB_OK;
+    HIPCHK(sync_all(e));
+    size_t pos_floats = (size_t)g.NCB * 4 * GG::PLANE;
+    if (dalloc(e, g.inp, (size_t)cap * GG::SLOTS * GG::CP) || dalloc(e, g.act[0], (size_t)cap * pos_floats) ||
+        dalloc(e, g.act[1], (size_t)cap * pos_floats))
+        return BB_ERR_HIP; // zero-filled: the halo ring of every position stays zero for the buffers' lifetime
+    g.cap = cap;
+    return BB_OK;
+}
+
+static int load_general_weights(bb_engine *e, const bb_net_weights *w) {
+    const int F = w->F, C = w->C, R = w->R, NCB = F / 16;
+    const int steps0 = (9 * C + 3) / 4;
+    std::vector<float> w0((size_t)NCB * steps0 * 64), wt((size_t)2 * R * NCB * 9 * NCB * 64 * 4), epi((size_t)(1 + 2 * R) * NCB * 48);
+    for (int fb = 0; fb < NCB; fb++)
+        for (int s = 0; s < steps0; s++)
+            for (int lane = 0; lane < 64; lane++) {
+                int f = lane & 15, j = lane >> 4, k = 4 * s + j;
+                w0[((size_t)fb * steps0 + s) * 64 + lane] = k < 9 * C ? w->conv0_k[(size_t)k * F + 16 * fb + f] : 0.f;
+            }
+    for (int l = 0; l < 2 * R; l++)
+        for (int fb = 0; fb < NCB; fb++)
+            for (int tap = 0; tap < 9; tap++)
+                for (int cb = 0; cb < NCB; cb++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int r = 0; r < 4; r++) {
+                            int f = lane & 15, j = lane >> 4, c = 16 * cb + 4 * j + r;
+                            wt[((((((size_t)l * NCB + fb) * 9 + tap) * NCB + cb) * 64) + lane) * 4 + r] =
+                                w->blk_k[(((size_t)l * 9 + tap) * F + c) * F + 16 * fb + f];
+                        }
+    std::vector<float> sc(F), sh(F);
+    for (int l = 0; l < 1 + 2 * R; l++) {
+        const float *b = l == 0 ? w->conv0_b : w->blk_b + (size_t)(l - 1) * F;
+        const float *bn = l == 0 ? w->conv0_bn : w->blk_bn + (size_t)(l - 1) * 4 * F;
+        bn_fold(bn, F, sc.data(), sh.data());
+        for (int fb = 0; fb < NCB; fb++) {
+            float *o = &epi[((size_t)l * NCB + fb) * 48];
+            memcpy(o, b + 16 * fb, 64);
+            memcpy(o + 16, sc.data() + 16 * fb, 64);
+            memcpy(o + 32, sh.data() + 16 * fb, 64);
+        }
+    }
+    GNetDev &g = e->gnet;
+    g = GNetDev{};
+    g.F = F;
+    g.NCB = NCB;
+    g.R = R;
+    float *d_w0, *d_wt, *d_epi;
+    if (dalloc(e, d_w0, w0.size(), false) || dalloc(e, d_wt, wt.size(), false) || dalloc(e, d_epi, epi.size(), false))
+        return BB_ERR_HIP;
+    HIPCHK(hipMemcpy(d_w0, w0.data(), w0.size() * 4, hipMemcpyHostToDevice));
+    if (!wt.empty()) HIPCHK(hipMemcpy(d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_epi, epi.data(), epi.size() * 4, hipMemcpyHostToDevice));
+    g.w0 = d_w0;
+    g.wt = (const f32x4 *)d_wt;
+    g.epi = d_epi;
+    return BB_OK;
+}
+
+// n_ptr != nullptr: the batch size lives in device memory (<= n_max); slot_list maps batch entries to mailbox slots
+template <class G>
+static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slot_list, const typename G::State *states,
+                       const int8_t *planes, const uint32_t *game_id, const int32_t *serial, int noise, float *value,
+                       float *logits, float *policy, int pstride, hipStream_t st) {
+    using GG = GNetGeom<G>;
+    int rc = gnet_reserve<G>(e, n_max);
+    if (rc) return rc;
+    const GNetDev &g = e->gnet;
+    k_gnet_input<G><<<nblk((size_t)n_max * GG::HW), 256, 0, st>>>(g, n_max, n_ptr, slot_list, states, planes);
+    dim3 grid((n_max + GG::PPB - 1) / GG::PPB, (g.NCB + 3) / 4);
+    k_gnet_conv<G, true><<<grid, 256, 0, st>>>(g, 0, n_max, n_ptr, nullptr, g.act[0], 0);
+    for (int l = 0; l < 2 * g.R; l++)
+        k_gnet_conv<G, false><<<grid, 256, 0, st>>>(g, 1 + l, n_max, n_ptr, g.act[l & 1], g.act[(l & 1) ^ 1], l & 1);
+    k_gnet_heads<G><<<(n_max + 3) / 4, 256, 0, st>>>(g, e->net, n_max, n_ptr, slot_list, g.act[0], game_id, serial, noise, value,
+                                                     logits, policy, pstride);
+    HIPCHK(hipGetLastError());
+    return BB_OK;
+}
+
 extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     if (!e || !w) return fail(BB_ERR_ARG, "null argument");
     const bb_game_info &gi = e->info;
     if (w->H != gi.H || w->W != gi.W || w->C != gi.C || w->A != gi.A)
         return fail(BB_ERR_ARG, "weights are for a %dx%dx%d/%d network, game needs %dx%dx%d/%d", w->H, w->W, w->C,
                     w->A, gi.H, gi.W, gi.C, gi.A);
-    if (w->F != 16) return fail(BB_ERR_ARG, "this build carries the fused F=16 tower only (got filters=%d)", w->F);
+    if (w->F <= 0 || w->F % 16 != 0 || w->F > 1024)
+        return fail(BB_ERR_ARG, "filters must be a multiple of 16 (MFMA tile), got %d", w->F);
     if (w->D <= 0 || w->D > 64 || w->R < 0) return fail(BB_ERR_ARG, "unsupported dense/blocks");
     HIPCHK(hipSetDevice(e->cfg.device));
-    const int F = 16, C = w->C, R = w->R, D = w->D, A = w->A;
+    const int F = w->F, C = w->C, R = w->R, D = w->D, A = w->A;
     const int steps0 = (9 * C + 3) / 4;
+    e->general_net = F != 16 || (getenv("BB_GNET") && atoi(getenv("BB_GNET")) != 0);
+    if (e->general_net) {
+        int rc = load_general_weights(e, w);
+        if (rc) return rc;
+    }
     std::vector<float> w0((size_t)steps0 * 64), wt((size_t)2 * R * 9 * 64 * 4), epi((size_t)(1 + 2 * R) * 48);
+    if (F == 16) // operands of the fused single-wave tower (net.hip.h)
     for (int s = 0; s < steps0; s++)
         for (int lane = 0; lane < 64; lane++) {
             int f = lane & 15, j = lane >> 4, k = 4 * s + j;
             w0[(size_t)s * 64 + lane] = k < 9 * C ? w->conv0_k[(size_t)k * F + f] : 0.f;
         }
+    if (F == 16)
     for (int l = 0; l < 2 * R; l++)
         for (int tap = 0; tap < 9; tap++)
             for (int lane = 0; lane < 64; lane++)
@@ -483,7 +580,7 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
                     int f = lane & 15, j = lane >> 4, c = 4 * j + r;
                     wt[(((size_t)l * 9 + tap) * 64 + lane) * 4 + r] = w->blk_k[(((size_t)l * 9 + tap) * F + c) * F + f];
                 }
-    for (int l = 0; l < 1 + 2 * R; l++) {
+    for (int l = 0; F == 16 && l < 1 + 2 * R; l++) {
         const float *b = l == 0 ? w->conv0_b : w->blk_b + (size_t)(l - 1) * F;
         const float *bn = l == 0 ? w->conv0_bn : w->blk_bn + (size_t)(l - 1) * 4 * F;
         memcpy(&epi[(size_t)l * 48], b, F * sizeof(float));
@@ -548,6 +645,8 @@ template <class G>
 static int launch_net(bb_engine *e, int n, const typename G::State *states, const int8_t *planes,
                       const uint32_t *game_id, const int32_t *serial, int noise, float *value, float *logits,
                       float *policy, int pstride, hipStream_t st) {
+    if (e->general_net)
+        return launch_gnet<G>(e, n, nullptr, nullptr, states, planes, game_id, serial, noise, value, logits, policy, pstride, st);
     constexpr int PW = NetPW<G>::v;
     int blocks = (n + 4 * PW - 1) / (4 * PW);
     k_net_fused16<G, PW><<<blocks, 256, 0, st>>>(e->net, n, states, planes, game_id, serial, noise, value, logits,
@@ -860,7 +959,7 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
         return fail(BB_ERR_ARG, "asynchronous self-play is for the dense-action games");
     } else {
         constexpr int PWMAX = NetPW<G>::v;
-        if (e->mega && e->net.R <= MEGA_RMAX && e->net.head_floats <= MEGA_HEAD_FLOATS) { // one persistent launch: `rounds` visits of every game == 2*rounds phases
+        if (e->mega && !e->general_net && e->net.R <= MEGA_RMAX && e->net.head_floats <= MEGA_HEAD_FLOATS) { // one persistent launch: `rounds` visits of every game == 2*rounds phases
             TreeDev &d = e->dev;
             int nb = (d.n_slots + 15) / 16;
             bool timed = e->time_every > 0 && e->ev_used + 2 <= e->ev_pool.size();
@@ -910,6 +1009,11 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
                     bool timed = v == 0 && e->time_every > 0 && (e->eval_launches++ % (uint64_t)e->time_every) == 0 &&
                                  e->ev_used + 2 <= e->ev_pool.size();
                     if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], st));
+                    if (e->general_net) {
+                        int rc = launch_gnet<G>(e, d.n_slots, d.post_count + (round & 3), d.post_slot, ls, nullptr, d.leaf_game_id,
+                                                d.leaf_serial, e->cfg.noise_on, d.eval_value, nullptr, d.eval_policy, G::S, st);
+                        if (rc) return rc;
+                    } else
                     k_net_compact<G, PWMAX><<<nb, 256, 0, st>>>(e->net, d.post_count + (round & 3), d.post_slot, ls,
                                                                  d.leaf_game_id, d.leaf_serial, e->cfg.noise_on, d.eval_value,
                                                                  d.eval_policy, G::S);

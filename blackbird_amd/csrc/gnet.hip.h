@@ -1,0 +1,206 @@
+// gnet.hip.h -- the network for ANY filter count F = 16*NCB (BASELINE configs[4]: 20 blocks x 256 filters).
+//
+// The fused kernels in net.hip.h keep a whole F=16 tower in one wave's LDS.  At F=256 one position's activations
+// are 43 KB per layer and one layer's weights 2.4 MB, so the tower becomes what it is on any machine: one
+// implicit-GEMM launch per conv layer (M = batch x H x W pixels, N = F, K = 9 F), activations ping-ponging
+// between two HBM buffers that stay L2/MALL resident, on v_mfma_f32_16x16x4_f32.
+//
+//  * activation layout  act[pos][cb][j][slot][4]   (cb = 16-channel block, j = 4-channel group, slot = pixel
+//    incl. a zero halo ring that is never written): the 16 pixels of an MFMA tile x 16 B are contiguous, the 9 taps
+//    are constant offsets, no bounds checks anywhere;
+//  * a workgroup = 4 waves = 4 consecutive 16-filter blocks of the SAME GN_PPB positions, so the B operand
+//    (activations) of a (tap, cb) step is shared through L1 by the 4 waves; each wave streams its own
+//    pre-swizzled A operand (weights) once per GN_NT pixel tiles;
+//  * K order per output pixel is (tap, 16-channel block, r, j), c = 16 cb + 4 j + r -- exactly the oracle's fmaf
+//    chain (its conv3x3), so the tower stays bit-comparable with the CPU restatement the tests check against;
+//  * heads: one wave per position runs the two 1x1 convolutions over F channels, then net_head_tail (shared with
+//    the fused kernels).
+// Every kernel takes the batch size from device memory when n_ptr != nullptr (compacted leaf lists of the
+// asynchronous search) and indexes mailboxes through slot_list when given.
+#pragma once
+#include "net.hip.h"
+
+struct GNetDev {
+    int F, NCB, R;            // filters, F/16, residual blocks
+    const float *w0;          // [NCB][steps0][64]            first conv, A-operand lane order per filter block
+    const f32x4 *wt;          // [2R][NCB(fb)][9][NCB(cb)][64] tower convs: lane (f=l&15, j=l>>4), .r = W[tap][16cb+4j+r][16fb+f]
+    const float *epi;         // [1+2R][NCB][3][16]           bias, bn scale, bn shift per filter block
+    float *inp;               // [cap][SLOTS][CP]             input planes as floats, zero halo
+    float *act[2];            // [cap][NCB][4][SLOTS][4]      ping-pong activations, zero halo
+    int cap;                  // positions the buffers hold (a multiple of GN_PPB)
+};
+
+template <class G>
+struct GNetGeom {
+    static constexpr int H = G::H, W = G::W, CIN = G::C, HW = H * W;
+    static constexpr int SLOTS = (H + 2) * (W + 1) + 1;
+    static constexpr int CP = (CIN + 3) / 4 * 4;
+    static constexpr int STEPS0 = (9 * CIN + 3) / 4;
+    // positions per workgroup: chosen so that PPB*HW fills whole 16-pixel tiles (or nearly)
+    static constexpr int PPB = HW == 42 ? 4 : (HW == 9 ? 16 : 2);
+    static constexpr int NT = (PPB * HW + 15) / 16; // C4: 11 tiles (10.5 used), TTT: 9 (exact), DragonChess: 8 (exact)
+    static constexpr int PLANE = SLOTS * 4;         // floats of one (cb, j) plane of one position
+};
+
+// ---- input planes: one thread per (position, cell) ------------------------------------------------------------
+template <class G>
+__global__ void __launch_bounds__(256) k_gnet_input(GNetDev gd, int n_max, const int *n_ptr, const int *slot_list,
+                                                    const typename G::State *states, const int8_t *planes) {
+    using GG = GNetGeom<G>;
+    const int n = n_ptr ? *n_ptr : n_max;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * GG::HW) return;
+    int i = (int)(t / GG::HW), cell = (int)(t % GG::HW), y = cell / GG::W, x = cell % GG::W;
+    float *dst = gd.inp + ((size_t)i * GG::SLOTS + (y + 1) * (GG::W + 1) + (x + 1)) * GG::CP;
+    if (planes) {
+        const int8_t *src = planes + ((size_t)i * GG::HW + cell) * GG::CIN;
+        for (int c = 0; c < GG::CIN; c++) dst[c] = (float)src[c];
+    } else {
+        int8_t v[GG::CIN];
+        G::encode_cell(states[slot_list ? slot_list[i] : i], y, x, v);
+        for (int c = 0; c < GG::CIN; c++) dst[c] = (float)v[c];
+    }
+}
+
+// ---- one conv layer (first conv when FIRST, else tower layer l) for GN_PPB positions x 64 filters per workgroup ---
+template <class G, bool FIRST>
+__global__ void __launch_bounds__(256) k_gnet_conv(GNetDev gd, int layer, int n_max, const int *n_ptr, const float *in,
+                                                   float *out, int skip) {
+    using GG = GNetGeom<G>;
+    constexpr int HW = GG::HW, W = GG::W, SLOTS = GG::SLOTS, CP = GG::CP, NT = GG::NT, PPB = GG::PPB, PLANE = GG::PLANE,
+                  CIN = GG::CIN, STEPS0 = GG::STEPS0;
+    const int n = n_ptr ? *n_ptr : n_max;
+    const int pos0 = blockIdx.x * PPB;
+    if (pos0 >= n) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane >> 4, nn = lane & 15;
+    const int fb = blockIdx.y * 4 + wave;
+    if (fb >= gd.NCB) return;
+    const int NCB = gd.NCB;
+    const size_t pos_floats = (size_t)NCB * 4 * PLANE; // activation floats per position
+
+    // per-tile addressing: lane (j, nn) <-> pixel nn of the tile
+    int boff[NT];  // float offset of (pos, plane j of block 0, slot) in the input (tower) / of (pos, slot) in inp (first conv)
+    int ooff[NT];  // float offset of (pos, fb, j, slot) in the output
+    bool valid[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        int q = t * 16 + nn;
+        int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
+        valid[t] = pp < PPB && pos0 + pp < n;
+        if (pp >= PPB) pp = PPB - 1; // a padded tile column: any readable address, result discarded
+        int slot = (y + 1) * (W + 1) + (x + 1);
+        if (FIRST) boff[t] = (pp * SLOTS + slot) * CP;
+        else boff[t] = (int)(pp * pos_floats) + j * PLANE + slot * 4;
+        ooff[t] = (int)(pp * pos_floats) + (fb * 4 + j) * PLANE + slot * 4;
+    }
+    const float *ep = gd.epi + ((size_t)layer * NCB + fb) * 48;
+    const f32x4 bias = *(const f32x4 *)(ep + 4 * j), scale = *(const f32x4 *)(ep + 16 + 4 * j),
+                shift = *(const f32x4 *)(ep + 32 + 4 * j);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = bias;
+
+    if constexpr (FIRST) {
+        const float *ip = gd.inp + (size_t)pos0 * SLOTS * CP;
+        const float *w0 = gd.w0 + (size_t)fb * STEPS0 * 64;
+#pragma unroll
+        for (int s = 0; s < STEPS0; s++) {
+            int kk0 = 4 * s + j;
+            int kk = kk0 < 9 * CIN ? kk0 : 9 * CIN - 1; // padded k: weight is 0
+            int tap = kk / CIN, c = kk % CIN;
+            int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * CP + c;
+            float a = w0[s * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ip[boff[t] + toff], acc[t], 0, 0, 0);
+        }
+    } else {
+        const float *ip = in + (size_t)pos0 * pos_floats;
+        const f32x4 *wp = gd.wt + (((size_t)(layer - 1) * NCB + fb) * 9) * NCB * 64 + lane;
+        // software pipeline over the 9*NCB (tap, cb) steps: the operands of step s+1 are in flight while the
+        // 4*NT MFMAs of step s issue
+        f32x4 a_cur = wp[0], a_nxt = a_cur;
+        f32x4 b_cur[NT], b_nxt[NT];
+        {
+            const int toff = (-(W + 1) - 1) * 4;
+#pragma unroll
+            for (int t = 0; t < NT; t++) b_cur[t] = *(const f32x4 *)(ip + boff[t] + toff);
+        }
+        const int steps = 9 * NCB;
+        int tap = 0, cb = 0;
+        for (int s = 0; s < steps; s++) {
+            int ncb = cb + 1, ntap = tap;
+            if (ncb == NCB) {
+                ncb = 0;
+                ntap = tap + 1;
+            }
+            if (s + 1 < steps) {
+                const int toff = ((ntap / 3 - 1) * (W + 1) + (ntap % 3 - 1)) * 4 + ncb * 4 * PLANE;
+                a_nxt = wp[(size_t)(s + 1) * 64];
+#pragma unroll
+                for (int t = 0; t < NT; t++) b_nxt[t] = *(const f32x4 *)(ip + boff[t] + toff);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r], b_cur[t][r], acc[t], 0, 0, 0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int t = 0; t < NT; t++) b_cur[t] = b_nxt[t];
+            tap = ntap;
+            cb = ncb;
+        }
+    }
+    float *op = out + (size_t)pos0 * pos_floats;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        f32x4 y;
+        f32x4 sk = {0.f, 0.f, 0.f, 0.f};
+        if (skip && valid[t]) sk = *(const f32x4 *)(op + ooff[t]); // tf.add(batch_norm_2, block input) before the ReLU
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float v = __builtin_fmaf(acc[t][r], scale[r], shift[r]);
+            if (skip) v = v + sk[r];
+            y[r] = fmaxf(v, 0.f);
+        }
+        if (valid[t]) *(f32x4 *)(op + ooff[t]) = y;
+    }
+}
+
+// ---- heads: one wave per position ----------------------------------------------------------------------------------
+template <class G>
+__global__ void __launch_bounds__(256) k_gnet_heads(GNetDev gd, NetDev nd, int n_max, const int *n_ptr, const int *slot_list,
+                                                    const float *act, const uint32_t *game_id, const int32_t *serial,
+                                                    int noise, float *value_out, float *logits_out, float *policy_out,
+                                                    int pstride) {
+    using GG = GNetGeom<G>;
+    constexpr int HW = GG::HW, W = GG::W, PLANE = GG::PLANE, A = G::A;
+    __shared__ float scratch[4][3 * HW + 64 + 2 * (A <= 64 ? A : 0) + 8];
+    const int n = n_ptr ? *n_ptr : n_max;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pos = blockIdx.x * 4 + wave;
+    if (pos >= n) return;
+    float *rv = scratch[wave], *rp = rv + HW, *sd = rp + 2 * HW, *lg = sd + nd.D;
+    const float *hp = nd.head;
+    const float *vk = hp + nd.off_vk, *v3 = hp + nd.off_v3, *pk = hp + nd.off_pk, *p6 = hp + nd.off_p6;
+    const float *ap = act + (size_t)pos * gd.NCB * 4 * PLANE;
+    for (int q = lane; q < HW; q += 64) { // channels in natural order c = 16 cb + 4 j + r (oracle: plain ascending c)
+        int y = q / W, x = q % W, slot = (y + 1) * (W + 1) + (x + 1);
+        float av = v3[0], a0 = p6[0], a1 = p6[1];
+        for (int cj = 0; cj < gd.NCB * 4; cj++) {
+            f32x4 xv = *(const f32x4 *)(ap + (size_t)cj * PLANE + slot * 4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int c = 4 * cj + r;
+                av = __builtin_fmaf(xv[r], vk[c], av);
+                a0 = __builtin_fmaf(xv[r], pk[2 * c], a0);
+                a1 = __builtin_fmaf(xv[r], pk[2 * c + 1], a1);
+            }
+        }
+        rv[q] = fmaxf(__builtin_fmaf(av, v3[1], v3[2]), 0.f);
+        rp[2 * q] = fmaxf(__builtin_fmaf(a0, p6[2], p6[4]), 0.f);
+        rp[2 * q + 1] = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
+    }
+    net_head_tail<G, 1>(nd, n, pos, slot_list, rv, rp, sd, lg, game_id, serial, noise, value_out, logits_out, policy_out,
+                        pstride, nullptr);
+}

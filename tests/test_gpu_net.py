@@ -106,10 +106,13 @@ def test_noise_distribution():
 def test_tree_with_net_matches_oracle_tree_on_gpu_values(orc):
     """End to end with the real network: the oracle's tree search, fed the GPU network's outputs
     through its callback evaluator, must reproduce the engine's visit counts exactly."""
-    import ctypes as C
+    _selfplay_vs_oracle_tree(orc, filters=16, blocks=4)
+
+
+def _selfplay_vs_oracle_tree(orc, filters, blocks):
     game, og = _lib.GAME_CONNECT4, 0
     gi = _lib.game_info(game)
-    w = W.init_weights(gi.C, 16, 4, 16, gi.A, seed=21)
+    w = W.init_weights(gi.C, filters, blocks, 16, gi.A, seed=21)
     flat = W.flatten(w)
     n_games, sims = 6, 40
     eng = _lib.Engine(game, n_slots=8, sims_per_move=sims, evaluator=_lib.EVAL_NET, seed=17, max_games=n_games)
