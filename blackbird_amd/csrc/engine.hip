@@ -491,12 +491,12 @@ static int load_general_weights(bb_engine *e, const bb_net_weights *w) {
             }
     for (int l = 0; l < 2 * R; l++)
         for (int fb = 0; fb < NCB; fb++)
-            for (int tap = 0; tap < 9; tap++)
-                for (int cb = 0; cb < NCB; cb++)
+            for (int cb = 0; cb < NCB; cb++)
+                for (int tap = 0; tap < 9; tap++)
                     for (int lane = 0; lane < 64; lane++)
                         for (int r = 0; r < 4; r++) {
                             int f = lane & 15, j = lane >> 4, c = 16 * cb + 4 * j + r;
-                            wt[((((((size_t)l * NCB + fb) * 9 + tap) * NCB + cb) * 64) + lane) * 4 + r] =
+                            wt[((((((size_t)l * NCB + fb) * NCB + cb) * 9 + tap) * 64) + lane) * 4 + r] =
                                 w->blk_k[(((size_t)l * 9 + tap) * F + c) * F + 16 * fb + f];
                         }
     std::vector<float> sc(F), sh(F);
@@ -538,10 +538,13 @@ static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slo
     if (rc) return rc;
     const GNetDev &g = e->gnet;
     k_gnet_input<G><<<nblk((size_t)n_max * GG::HW), 256, 0, st>>>(g, n_max, n_ptr, slot_list, states, planes);
-    dim3 grid((n_max + GG::PPB - 1) / GG::PPB, (g.NCB + 3) / 4);
-    k_gnet_conv<G, true><<<grid, 256, 0, st>>>(g, 0, n_max, n_ptr, nullptr, g.act[0], 0);
+    const int pairs = (g.NCB + GN_FBW - 1) / GN_FBW;
+    const int ppw = pairs >= 4 ? 4 : (pairs >= 2 ? 2 : 1); // filter-block pairs per workgroup
+    const int groups = (n_max + GG::PPB - 1) / GG::PPB;    // groups of PPB positions
+    dim3 grid((groups + 4 / ppw - 1) / (4 / ppw), (pairs + ppw - 1) / ppw);
+    k_gnet_conv<G, true><<<grid, 256, 0, st>>>(g, 0, n_max, n_ptr, nullptr, g.act[0], 0, ppw);
     for (int l = 0; l < 2 * g.R; l++)
-        k_gnet_conv<G, false><<<grid, 256, 0, st>>>(g, 1 + l, n_max, n_ptr, g.act[l & 1], g.act[(l & 1) ^ 1], l & 1);
+        k_gnet_conv<G, false><<<grid, 256, 0, st>>>(g, 1 + l, n_max, n_ptr, g.act[l & 1], g.act[(l & 1) ^ 1], l & 1, ppw);
     k_gnet_heads<G><<<(n_max + 3) / 4, 256, 0, st>>>(g, e->net, n_max, n_ptr, slot_list, g.act[0], game_id, serial, noise, value,
                                                      logits, policy, pstride);
     HIPCHK(hipGetLastError());

@@ -8,10 +8,12 @@
 //  * activation layout  act[pos][cb][j][slot][4]   (cb = 16-channel block, j = 4-channel group, slot = pixel
 //    incl. a zero halo ring that is never written): the 16 pixels of an MFMA tile x 16 B are contiguous, the 9 taps
 //    are constant offsets, no bounds checks anywhere;
-//  * a workgroup = 4 waves = 4 consecutive 16-filter blocks of the SAME GN_PPB positions, so the B operand
-//    (activations) of a (tap, cb) step is shared through L1 by the 4 waves; each wave streams its own
-//    pre-swizzled A operand (weights) once per GN_NT pixel tiles;
-//  * K order per output pixel is (tap, 16-channel block, r, j), c = 16 cb + 4 j + r -- exactly the oracle's fmaf
+//  * a wave = 2 filter blocks x NT pixel tiles; a workgroup = 4 waves = 8 consecutive 16-filter blocks of the SAME
+//    PPB positions, so the B operand (activations) of a (tap, cb) step is shared through L1 by the 4 waves; each
+//    wave streams its own pre-swizzled A operands (weights) once per NT pixel tiles;
+//  * K order per output pixel is (16-channel block, tap, r, j), c = 16 cb + 4 j + r: the 9 shifted views of one
+//    channel block (17 KB for 4 positions) are consumed together, so they are L1/L2 hits instead of 9 passes over
+//    the whole activation tensor -- and it is exactly the CPU restatement's fmaf
 //    chain (its conv3x3), so the tower stays bit-comparable with the CPU restatement the tests check against;
 //  * heads: one wave per position runs the two 1x1 convolutions over F channels, then net_head_tail (shared with
 //    the fused kernels).
@@ -23,7 +25,7 @@
 struct GNetDev {
     int F, NCB, R;            // filters, F/16, residual blocks
     const float *w0;          // [NCB][steps0][64]            first conv, A-operand lane order per filter block
-    const f32x4 *wt;          // [2R][NCB(fb)][9][NCB(cb)][64] tower convs: lane (f=l&15, j=l>>4), .r = W[tap][16cb+4j+r][16fb+f]
+    const f32x4 *wt;          // [2R][NCB(fb)][NCB(cb)][9][64] tower convs: lane (f=l&15, j=l>>4), .r = W[tap][16cb+4j+r][16fb+f]
     const float *epi;         // [1+2R][NCB][3][16]           bias, bn scale, bn shift per filter block
     float *inp;               // [cap][SLOTS][CP]             input planes as floats, zero halo
     float *act[2];            // [cap][NCB][4][SLOTS][4]      ping-pong activations, zero halo
@@ -62,25 +64,39 @@ __global__ void __launch_bounds__(256) k_gnet_input(GNetDev gd, int n_max, const
     }
 }
 
-// ---- one conv layer (first conv when FIRST, else tower layer l) for GN_PPB positions x 64 filters per workgroup ---
+// ---- one conv layer (first conv when FIRST, else tower layer l) ---------------------------------------------------
+// A wave owns GN_FBW = 2 filter blocks x NT pixel tiles of PPB positions: the B operand (activations) it loads for a
+// (tap, cb) step feeds 2 x NT x 4 MFMAs and each A operand NT x 4, i.e. 13 KB of operand loads per 88 MFMAs --
+// half the L1 traffic of one filter block per wave.  A workgroup = 4 waves = 8 consecutive filter blocks of the
+// same positions (their B loads hit L1).
+#define GN_FBW 2
 template <class G, bool FIRST>
 __global__ void __launch_bounds__(256) k_gnet_conv(GNetDev gd, int layer, int n_max, const int *n_ptr, const float *in,
-                                                   float *out, int skip) {
+                                                   float *out, int skip, int pairs_per_wg) {
     using GG = GNetGeom<G>;
     constexpr int HW = GG::HW, W = GG::W, SLOTS = GG::SLOTS, CP = GG::CP, NT = GG::NT, PPB = GG::PPB, PLANE = GG::PLANE,
-                  CIN = GG::CIN, STEPS0 = GG::STEPS0;
+                  CIN = GG::CIN, STEPS0 = GG::STEPS0, FBW = GN_FBW;
     const int n = n_ptr ? *n_ptr : n_max;
-    const int pos0 = blockIdx.x * PPB;
-    if (pos0 >= n) return;
+    // the 4 waves of a workgroup = pairs_per_wg (1, 2 or 4) filter-block pairs x 4/pairs_per_wg groups of PPB positions,
+    // so that narrow networks (F < 128) still use every wave
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane >> 4, nn = lane & 15;
-    const int fb = blockIdx.y * 4 + wave;
-    if (fb >= gd.NCB) return;
+    const int pos0 = (blockIdx.x * (4 / pairs_per_wg) + wave / pairs_per_wg) * PPB;
+    if (pos0 >= n) return;
     const int NCB = gd.NCB;
+    const int fb0 = (blockIdx.y * pairs_per_wg + wave % pairs_per_wg) * FBW;
+    if (fb0 >= NCB) return;
+    int fbs[FBW]; // an odd filter-block count leaves the last wave's second block unused: computed on block NCB-1, not stored
+    bool fb_ok[FBW];
+#pragma unroll
+    for (int f = 0; f < FBW; f++) {
+        fb_ok[f] = fb0 + f < NCB;
+        fbs[f] = fb_ok[f] ? fb0 + f : NCB - 1;
+    }
     const size_t pos_floats = (size_t)NCB * 4 * PLANE; // activation floats per position
 
     // per-tile addressing: lane (j, nn) <-> pixel nn of the tile
     int boff[NT];  // float offset of (pos, plane j of block 0, slot) in the input (tower) / of (pos, slot) in inp (first conv)
-    int ooff[NT];  // float offset of (pos, fb, j, slot) in the output
+    int ooff[NT];  // float offset of (pos, plane j of block 0, slot) in the output
     bool valid[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -89,81 +105,103 @@ __global__ void __launch_bounds__(256) k_gnet_conv(GNetDev gd, int layer, int n_
         valid[t] = pp < PPB && pos0 + pp < n;
         if (pp >= PPB) pp = PPB - 1; // a padded tile column: any readable address, result discarded
         int slot = (y + 1) * (W + 1) + (x + 1);
-        if (FIRST) boff[t] = (pp * SLOTS + slot) * CP;
-        else boff[t] = (int)(pp * pos_floats) + j * PLANE + slot * 4;
-        ooff[t] = (int)(pp * pos_floats) + (fb * 4 + j) * PLANE + slot * 4;
+        ooff[t] = (int)(pp * pos_floats) + j * PLANE + slot * 4;
+        boff[t] = FIRST ? (pp * SLOTS + slot) * CP : ooff[t];
     }
-    const float *ep = gd.epi + ((size_t)layer * NCB + fb) * 48;
-    const f32x4 bias = *(const f32x4 *)(ep + 4 * j), scale = *(const f32x4 *)(ep + 16 + 4 * j),
-                shift = *(const f32x4 *)(ep + 32 + 4 * j);
-    f32x4 acc[NT];
+    f32x4 acc[FBW][NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = bias;
+    for (int f = 0; f < FBW; f++) {
+        const f32x4 bias = *(const f32x4 *)(gd.epi + ((size_t)layer * NCB + fbs[f]) * 48 + 4 * j);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[f][t] = bias;
+    }
 
     if constexpr (FIRST) {
         const float *ip = gd.inp + (size_t)pos0 * SLOTS * CP;
-        const float *w0 = gd.w0 + (size_t)fb * STEPS0 * 64;
 #pragma unroll
         for (int s = 0; s < STEPS0; s++) {
             int kk0 = 4 * s + j;
             int kk = kk0 < 9 * CIN ? kk0 : 9 * CIN - 1; // padded k: weight is 0
             int tap = kk / CIN, c = kk % CIN;
             int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * CP + c;
-            float a = w0[s * 64 + lane];
+            float a[FBW];
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ip[boff[t] + toff], acc[t], 0, 0, 0);
+            for (int f = 0; f < FBW; f++) a[f] = gd.w0[((size_t)fbs[f] * STEPS0 + s) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                float b = ip[boff[t] + toff];
+#pragma unroll
+                for (int f = 0; f < FBW; f++) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f], b, acc[f][t], 0, 0, 0);
+            }
         }
     } else {
         const float *ip = in + (size_t)pos0 * pos_floats;
-        const f32x4 *wp = gd.wt + (((size_t)(layer - 1) * NCB + fb) * 9) * NCB * 64 + lane;
-        // software pipeline over the 9*NCB (tap, cb) steps: the operands of step s+1 are in flight while the
-        // 4*NT MFMAs of step s issue
-        f32x4 a_cur = wp[0], a_nxt = a_cur;
-        f32x4 b_cur[NT], b_nxt[NT];
-        {
-            const int toff = (-(W + 1) - 1) * 4;
+        const f32x4 *wp[FBW];
 #pragma unroll
-            for (int t = 0; t < NT; t++) b_cur[t] = *(const f32x4 *)(ip + boff[t] + toff);
-        }
+        for (int f = 0; f < FBW; f++) wp[f] = gd.wt + (((size_t)(layer - 1) * NCB + fbs[f]) * 9) * NCB * 64 + lane;
+        // software pipeline over the NCB*9 (cb, tap) steps, two register sets used alternately (no copies): the
+        // operands of step s+1 are in flight while the FBW*4*NT MFMAs of step s issue
+        f32x4 a0[FBW], a1[FBW], b0[NT], b1[NT];
         const int steps = 9 * NCB;
-        int tap = 0, cb = 0;
-        for (int s = 0; s < steps; s++) {
-            int ncb = cb + 1, ntap = tap;
-            if (ncb == NCB) {
-                ncb = 0;
-                ntap = tap + 1;
-            }
-            if (s + 1 < steps) {
-                const int toff = ((ntap / 3 - 1) * (W + 1) + (ntap % 3 - 1)) * 4 + ncb * 4 * PLANE;
-                a_nxt = wp[(size_t)(s + 1) * 64];
+        auto load_step = [&](f32x4 (&a)[FBW], f32x4 (&b)[NT], int s) {
+            const int cb = s / 9, tap = s - 9 * cb;
+            const int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * 4 + cb * 4 * PLANE;
 #pragma unroll
-                for (int t = 0; t < NT; t++) b_nxt[t] = *(const f32x4 *)(ip + boff[t] + toff);
-            }
+            for (int f = 0; f < FBW; f++) a[f] = wp[f][(size_t)s * 64];
+#pragma unroll
+            for (int t = 0; t < NT; t++) b[t] = *(const f32x4 *)(ip + boff[t] + toff);
+        };
+        auto mma_step = [&](const f32x4 (&a)[FBW], const f32x4 (&b)[NT]) {
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
                 for (int t = 0; t < NT; t++)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r], b_cur[t][r], acc[t], 0, 0, 0);
-            a_cur = a_nxt;
 #pragma unroll
-            for (int t = 0; t < NT; t++) b_cur[t] = b_nxt[t];
-            tap = ntap;
-            cb = ncb;
+                    for (int f = 0; f < FBW; f++)
+                        acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f][r], b[t][r], acc[f][t], 0, 0, 0);
+        };
+        // Prefetch distance two steps (three register sets in rotation; 9*NCB is a multiple of 3).  The scheduling
+        // barriers keep the compiler from sinking a step's loads down to their first use, which would put an L2
+        // round trip in front of every step.
+        f32x4 a2[FBW], b2[NT];
+        const int last = steps - 1;
+        load_step(a0, b0, 0);
+        load_step(a1, b1, 1 < last ? 1 : last);
+        for (int s = 0; s < steps; s += 3) {
+            load_step(a2, b2, s + 2 < last ? s + 2 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_step(a0, b0, s + 3 < last ? s + 3 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_step(a1, b1, s + 4 < last ? s + 4 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(a2, b2);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     float *op = out + (size_t)pos0 * pos_floats;
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        f32x4 y;
-        f32x4 sk = {0.f, 0.f, 0.f, 0.f};
-        if (skip && valid[t]) sk = *(const f32x4 *)(op + ooff[t]); // tf.add(batch_norm_2, block input) before the ReLU
+    for (int f = 0; f < FBW; f++) {
+        if (!fb_ok[f]) continue;
+        const float *ep = gd.epi + ((size_t)layer * NCB + fbs[f]) * 48;
+        const f32x4 scale = *(const f32x4 *)(ep + 16 + 4 * j), shift = *(const f32x4 *)(ep + 32 + 4 * j);
+        const int fo = fbs[f] * 4 * PLANE;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float v = __builtin_fmaf(acc[t][r], scale[r], shift[r]);
-            if (skip) v = v + sk[r];
-            y[r] = fmaxf(v, 0.f);
+        for (int t = 0; t < NT; t++) {
+            f32x4 y;
+            f32x4 sk = {0.f, 0.f, 0.f, 0.f};
+            if (skip && valid[t]) sk = *(const f32x4 *)(op + ooff[t] + fo); // tf.add(batch_norm_2, block input) before the ReLU
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = __builtin_fmaf(acc[f][t][r], scale[r], shift[r]);
+                if (skip) v = v + sk[r];
+                y[r] = fmaxf(v, 0.f);
+            }
+            if (valid[t]) *(f32x4 *)(op + ooff[t] + fo) = y;
         }
-        if (valid[t]) *(f32x4 *)(op + ooff[t]) = y;
     }
 }
 

@@ -12,9 +12,11 @@
  *
  * Summation order (a free choice -- TF's is unspecified): every dot product is a single
  * k-ordered fmaf chain starting from the bias.  The order inside a 3x3 tower conv is
- * (tap, 16-channel block, r, j) with c = 16*block + 4*j + r, which is the order in which a
+ * (16-channel block, tap, r, j) with c = 16*block + 4*j + r, which is the order in which a
  * v_mfma_f32_16x16x4_f32 chain on gfx950 consumes K when each lane group j holds channels
- * 4j..4j+3; the first conv (few input planes) uses the natural (tap, c) order.
+ * 4j..4j+3 and the 9 taps of one channel block are consumed together (cache locality of the
+ * wide networks; for 16 filters there is one block and the order is simply (tap, r, j));
+ * the first conv (few input planes) uses the natural (tap, c) order.
  */
 #include "orc.h"
 #include <math.h>
@@ -43,19 +45,25 @@ static void conv3x3(const float *in, float *out, const float *skip, int H, int W
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             for (int f = 0; f < F; f++) acc[f] = bias[f];
-            for (int t = 0; t < 9; t++) {
-                int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue; /* zero padding: fma(0,w,acc)==acc */
-                const float *ip = in + (yy * W + xx) * Cin;
-                const float *kp = k + (size_t)t * Cin * F;
-                if (natural_order) {
+            if (natural_order) {
+                for (int t = 0; t < 9; t++) {
+                    int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue; /* zero padding: fma(0,w,acc)==acc */
+                    const float *ip = in + (yy * W + xx) * Cin;
+                    const float *kp = k + (size_t)t * Cin * F;
                     for (int c = 0; c < Cin; c++) {
                         float a = ip[c];
                         const float *w = kp + (size_t)c * F;
                         for (int f = 0; f < F; f++) acc[f] = fmaf(a, w[f], acc[f]);
                     }
-                } else {
-                    for (int cb = 0; cb < Cin; cb += 16)
+                }
+            } else {
+                for (int cb = 0; cb < Cin; cb += 16)
+                    for (int t = 0; t < 9; t++) {
+                        int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                        const float *ip = in + (yy * W + xx) * Cin;
+                        const float *kp = k + (size_t)t * Cin * F;
                         for (int r = 0; r < 4; r++)
                             for (int j = 0; j < 4; j++) {
                                 int c = cb + 4 * j + r;
@@ -64,7 +72,7 @@ static void conv3x3(const float *in, float *out, const float *skip, int H, int W
                                 const float *w = kp + (size_t)c * F;
                                 for (int f = 0; f < F; f++) acc[f] = fmaf(a, w[f], acc[f]);
                             }
-                }
+                    }
             }
             float *o = out + (y * W + x) * F;
             for (int f = 0; f < F; f++) {

@@ -3,6 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from blackbird_amd import _lib, weights as W
+if os.environ.get("BB_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["BB_LIB"])
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
