@@ -37,7 +37,7 @@ def _check(orc, game, F, R, n, seed, perturb=True):
 
 
 @pytest.mark.parametrize("game", [_lib.GAME_CONNECT4, _lib.GAME_TICTACTOE])
-@pytest.mark.parametrize("F,R,n", [(32, 2, 1), (32, 2, 37), (64, 3, 9), (48, 1, 130)])
+@pytest.mark.parametrize("F,R,n", [(32, 2, 1), (32, 2, 37), (64, 3, 9), (48, 1, 130), (128, 2, 21)])
 def test_general_filters_vs_oracle(orc, game, F, R, n):
     _check(orc, game, F, R, n, seed=21)
 
