@@ -22,6 +22,9 @@
 // Measured on MI355X (4096 games, 800 sims): touching all 7 children's rows per level makes the
 // descent bandwidth-bound (46 MB/step) and is not faster than the plain dependent row load.
 #ifndef BB_PREFETCH_CHILDREN
+#ifndef BB_PREFETCH_BEST
+#define BB_PREFETCH_BEST 0
+#endif
 #define BB_PREFETCH_CHILDREN 0
 #endif
 #ifndef BB_MOVE_BODY_ATTR
@@ -837,6 +840,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
         typename G::State st;
         int flags = 0, expand = 0, overflow = 0;
         bool have = false, parked = false, leaf_found = false, term = false;
+        int pf_touch = 0; // speculative touch of the likeliest child's row (BB_PREFETCH_BEST)
         for (;;) {
             if (budget <= 0) { parked = true; break; }
             budget--;
@@ -854,7 +858,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
             double cPi = node->cP[lane];
             int ci = node->child[lane];
             double cached = node->pad0;
-            asm volatile("" ::"v"(flags_l), "v"(mask), "v"(sq), "v"(Ni), "v"(Qi), "v"(cPi), "v"(ci));
+            asm volatile("" ::"v"(flags_l), "v"(mask), "v"(sq), "v"(Ni), "v"(Qi), "v"(cPi), "v"(ci), "v"(pf_touch)); // (the previous level's touch is older than these loads)
 #ifdef BB_STAMPS_DEEP
             st_load += clock64() - ts0;
 #endif
@@ -890,6 +894,18 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
                 break;
             }
             if (mask == 0) { leaf_found = true; break; }
+#if BB_PREFETCH_BEST
+            { // the most visited child is the likeliest next step: pull its row towards this CU while the PUCT arithmetic runs
+                int key = (ci >= 0 && lane < A) ? ((Ni << 4) | lane) : -1;
+                int best = key;
+                best = max(best, dpp_step_i<0>(best));
+                best = max(best, dpp_step_i<1>(best));
+                best = max(best, dpp_step_i<2>(best));
+                if (S == 16) best = max(best, dpp_step_i<3>(best));
+                int bchild = __shfl(ci, best & 15, S);
+                if (best >= 0) pf_touch = ((const int *)(pool + (bchild & ~CHILD_TERM_BIT)))[lane * 8];
+            }
+#endif
             double u = puct_score(child_q(d, Qi, 0.f, Ni), cPi, sq, Ni, lane < A && ((mask >> lane) & 1u));
             int child = ci;
             int a = grp_argmax<S>(u, lane, child);
