@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--prefill", type=int, default=64, help="untimed de-synchronisation plies at 32 sims/move")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
+                    help="c2 = BASELINE configs[1] (default, the headline); c5 = the same game with the 20-block x "
+                         "256-filter network of configs[4] (one ply is 3.3 M evaluations: use --steps 1 --warmup 0 --prefill 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,7 +109,11 @@ def main():
 
     game = _lib.GAME_CONNECT4
     K, Wm = args.steps, args.warmup
-    flat = W.flatten(W.init_weights(3, 16, 4, 16, 7, seed=0))
+    blocks, filters = (20, 256) if args.workload == "c5" else (4, 16)
+    flat = W.flatten(W.init_weights(3, filters, blocks, 16, 7, seed=0))
+    # F_eval = 2 HW 9 C F + 4 R HW 9 F^2 + 6 HW F + 4 A + 4 D
+    flops_per_eval = 2 * 42 * 9 * 3 * filters + 4 * blocks * 42 * 9 * filters * filters + 6 * 42 * filters + 4 * 7 + 4 * 16
+    assert args.workload != "c2" or flops_per_eval == FLOPS_PER_EVAL
     total_plies = args.prefill + Wm + K + 2
     # every slot finishes at most one game per 7 plies (shortest Connect4 game)
     max_games = args.slots * (total_plies // 7 + 2)
@@ -171,10 +178,12 @@ def main():
                       3: "k_selfplay_queue<Connect4,8> (8 network + 4 tree waves per CU, LDS work queue)",
                       4: "k_selfplay_team<Connect4,2> (2 teams of 3 network waves + 6 tree waves per CU)"}[mode]
             launches = max(net_n, 1)
-            flops_per_launch = FLOPS_PER_EVAL * cnt["evals"] / launches
+            flops_per_launch = flops_per_eval * cnt["evals"] / launches
         else:
             kernel = "k_net_compact<Connect4,4>" if mode == 1 else "k_net_fused16<Connect4,4>"
-            flops_per_launch = FLOPS_PER_EVAL * cnt["evals"] / (K * args.sims)
+            if filters != 16:
+                kernel = "k_gnet_conv_lds<Connect4> x %d conv layers + first conv + heads per evaluation batch" % (2 * blocks)
+            flops_per_launch = flops_per_eval * cnt["evals"] / (K * args.sims)
         achieved = flops_per_launch / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
         out = {
             "metric": "selfplay_games_per_sec", "value": games / dt, "unit": "games/s",
@@ -182,9 +191,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (self-play from the initial position, random-init weights seed 0)",
             "config": {"workload": "Connect4 7x6, DynamicMCTS 800 sims/move, %d concurrent games per GPU, "
-                                   "net R4/F16/D16 fp32, noise alpha 0.2 eps 0.3 (BASELINE configs[1])" % args.slots,
+                                   "net R%d/F%d/D16 fp32, noise alpha 0.2 eps 0.3 (BASELINE configs[%d])"
+                                   % (args.slots, blocks, filters, 4 if args.workload == "c5" else 1),
                        "game": "Connect4", "sims_per_move": args.sims, "concurrent_games_per_gpu": args.slots,
-                       "blocks": 4, "filters": 16, "step": "800 tree+network rounds over all games (one ply in lock-step terms)",
+                       "blocks": blocks, "filters": filters, "step": "800 tree+network rounds over all games (one ply in lock-step terms)",
                        "launch_structure": ["lockstep", "async-rounds", "persistent-phases", "persistent-queue", "persistent-teams"][mode],
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
             "node_evals_per_sec": sims / dt, "net_evals_per_sec_rank0": cnt["evals"] / dt, "plies_per_sec": plies / dt,
@@ -200,7 +210,7 @@ def main():
         if allgather_s is not None:
             out["examples_allgather_s"] = allgather_s
             out["examples_gathered"] = n_examples_all
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             out["cpu_baseline"] = cpu_baseline(flat)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))

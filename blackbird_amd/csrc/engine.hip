@@ -440,7 +440,9 @@ extern "C" int bb_timing_read(bb_engine *e, double *mean_ms_out, double *min_ms_
 
 extern "C" int bb_selfplay_mode(bb_engine *e) {
     if (!e) return fail(BB_ERR_ARG, "null engine");
-    if (e->mega) return e->mega_queue == 2 ? 4 : (e->mega_queue == 1 ? 3 : 2);
+    // the persistent kernels carry a 16-filter network of at most MEGA_RMAX blocks in LDS; anything else runs as rounds
+    const bool fits = !e->has_weights || (!e->general_net && e->net.R <= MEGA_RMAX && e->net.head_floats <= MEGA_HEAD_FLOATS);
+    if (e->mega && fits) return e->mega_queue == 2 ? 4 : (e->mega_queue == 1 ? 3 : 2);
     return e->async_selfplay ? 1 : 0;
 }
 

@@ -3,24 +3,24 @@
 // k_selfplay_queue (mega2.hip.h) gives every leaf to one wave, and that wave needs ~30 us for it: the 3 MFMA
 // tiles of a 7x6 board run one after the other on one SIMD's matrix pipe.  With 16 games per CU the self-play
 // rate is set by the per-game round trip (tree descent -> evaluation -> apply), not by any pipe's throughput,
-// so here the evaluation itself is spread over T = 3 waves on three SIMDs:
-//     wave tw of a team owns the 16-pixel tiles tw, tw+T, ... of the (1 or 2) queued positions;
-//     activations live in the team's shared LDS region; after every conv layer the team synchronises through
-//     per-wave epoch words in LDS (no atomics, no workgroup barrier);
+// so here the evaluation itself is spread over a TEAM of T = 4 waves, one on each SIMD of the CU:
+//     a team takes 1..3 queued leaves at a time; wave tw owns the 16-pixel tiles tw, tw+4 of their 3 / 6 / 8 tiles;
+//     activations live in the team's shared LDS region (one layout, sized for 3 positions); after every conv layer
+//     the team synchronises through per-wave epoch words in LDS (no atomics, no workgroup barrier);
 //     after the tower, wave 0 computes the value head, wave 1 the policy head + softmax, wave 2 draws the
 //     Beta(alpha, 1-alpha) prior noise, and wave 1 mixes it in.
-// Every output pixel is still one wave's own MFMA chain in the oracle's K order, so results are bit-identical
-// to net_body's (tests/test_gpu_net.py, tests/test_gpu_mcts.py run against this kernel when it is the default).
-// A team takes two queued leaves at once when two are waiting (two chains per wave fill the MFMA pipe).
+// Two teams (waves 0-3 and 4-7) and four tree waves (8-11) put exactly one wave of each kind on every SIMD, so
+// the waves of a team progress at the same pace.  Every output pixel is still one wave's own MFMA chain in the
+// oracle's K order, so results are bit-identical to net_body's (tools/queue_cmp.py, GPU tests with BB_MEGA_QUEUE=2).
 #pragma once
 #include "mega2.hip.h"
 
 struct TeamCtl {
     int flag[4]; // flag[tw] = number of synchronisation points wave tw has passed
-    int slot[2]; // engine slots of the positions being evaluated
-    int li[2];   // their workgroup-local game indices
-    int n;       // 1 or 2 positions, -1 nothing queued, -2 finished
-    int pad[7];
+    int slot[4]; // engine slots of the positions being evaluated
+    int li[4];   // their workgroup-local game indices
+    int n;       // 1..3 positions, -1 nothing queued, -2 finished
+    int pad[3];
 };
 
 // publish "wave tw reached its next synchronisation point" (all lanes store the same word: no divergence)
@@ -55,65 +55,53 @@ __device__ __forceinline__ bool team_sync(TeamCtl *tc, int tw, int &epoch, Queue
     return true;
 }
 
-// One evaluation of n <= PW positions by a team of T waves; `tl` is the team's LDS region
-// (NetGeom<G,PW>::WAVE_FLOATS floats, zeroed once per launch).  Returns false when the launch was aborted.
-template <class G, int PW, int T>
-__device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int *slot_list, float *tl, TeamCtl *tc, int tw,
-                                              int &epoch, const typename G::State *states, const uint32_t *game_id,
-                                              const int32_t *serial, int noise, float *value_out, float *policy_out,
-                                              int pstride, QueueCtl *qc, long long t_start, long long t_limit, long long *tst = nullptr) {
 #ifdef BB_STAMPS
-    long long _ts = clock64();
-#define TSTAMP(i) do { long long _t = clock64(); if ((threadIdx.x & 63) == 0) tst[i] += _t - _ts; _ts = clock64(); } while (0)
+#define TSTAMP(i) do { long long _t = clock64(); if ((threadIdx.x & 63) == 0 && tst) tst[i] += _t - _ts; _ts = clock64(); } while (0)
+#define TS_ARG , long long *tst = nullptr
+#define TS_PASS , tst
+#define TS_INIT long long _ts = clock64();
 #else
 #define TSTAMP(i) do {} while (0)
+#define TS_ARG
+#define TS_PASS
+#define TS_INIT
 #endif
-    static_assert(T == 3, "head roles are written for teams of three waves");
+
+// One evaluation of n <= PW positions by a team of T waves; `tl` is the team's LDS region
+// (NetGeom<G,PW>::WAVE_FLOATS floats, zeroed once per launch; the layout does not depend on n, so the zero halo
+// survives any mix of batch sizes).  NTW = tiles this wave computes (0: it only keeps the team's synchronisation
+// points).  Returns false when the launch was aborted.
+template <class G, int PW, int T, int NTW>
+__device__ __forceinline__ bool net_team_tower(const NetDev &nd, int n, float *tl, TeamCtl *tc, int tw, int &epoch,
+                                               QueueCtl *qc, long long t_start, long long t_limit TS_ARG) {
+    TS_INIT
     using NG = NetGeom<G, PW>;
-    constexpr int W = NG::W, CIN = NG::CIN, A = NG::A, HW = NG::HW, SLOTS = NG::SLOTS, CP = NG::CP, NT = NG::NT,
-                  STEPS0 = NG::STEPS0, ACT = NG::ACT, PLANE = NG::PLANE;
-    constexpr int NTW = (NT + T - 1) / T; // tiles per wave
+    constexpr int W = NG::W, CIN = NG::CIN, HW = NG::HW, SLOTS = NG::SLOTS, CP = NG::CP, STEPS0 = NG::STEPS0, ACT = NG::ACT,
+                  PLANE = NG::PLANE;
     const int lane = threadIdx.x & 63;
     const int j = lane >> 4, nn = lane & 15;
     float *actA = tl;
     float *actB = actA + ACT;
-    float *inp = actB + ACT;
-
-    // ---- prologue: every wave of the team stages the same boards and planes (identical stores, no sync needed)
-    const int my_pp = lane % PW;
-    const typename G::State my_state = states[slot_list[my_pp < n ? my_pp : 0]];
-    float w0r[STEPS0];
-#pragma unroll
-    for (int s = 0; s < STEPS0; s++) w0r[s] = nd.w0[s * 64 + lane];
-    const f32x4 bias0 = *(const f32x4 *)(nd.epi + 4 * j), scale0 = *(const f32x4 *)(nd.epi + 16 + 4 * j),
-                shift0 = *(const f32x4 *)(nd.epi + 32 + 4 * j);
-    typename G::State *sst = (typename G::State *)(inp + PW * SLOTS * CP);
-    if (lane < PW) sst[lane] = my_state;
-    for (int q = lane; q < PW * HW; q += 64) {
-        int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
-        if (pp >= n) continue;
-        float *dst = inp + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * CP;
-        int8_t v[CIN];
-        G::encode_cell(sst[pp], y, x, v);
-#pragma unroll
-        for (int c = 0; c < CIN; c++) dst[c] = (float)v[c];
-    }
-    int aoff[NTW], ioff[NTW];
-    bool valid[NTW];
+    const float *inp = actB + ACT;
+    int aoff[NTW > 0 ? NTW : 1], ioff[NTW > 0 ? NTW : 1];
+    bool valid[NTW > 0 ? NTW : 1];
 #pragma unroll
     for (int k = 0; k < NTW; k++) {
         int q = (tw + T * k) * 16 + nn;
-        valid[k] = q < PW * HW && (tw + T * k) < NT;
-        int qq = valid[k] ? q : 0;
+        valid[k] = q < n * HW;
+        int qq = q < PW * HW ? q : 0;
         int pp = qq / HW, cell = qq % HW, y = cell / W, x = cell % W;
-        int slot = valid[k] ? (y + 1) * (W + 1) + (x + 1) : 0; // invalid lanes read the (zero) corner halo
+        int slot = (y + 1) * (W + 1) + (x + 1);
         aoff[k] = j * PLANE + (pp * SLOTS + slot) * 4;
         ioff[k] = (pp * SLOTS + slot) * CP;
     }
-    TSTAMP(0);
-    f32x4 acc[NTW];
-    // ---- first conv (this wave's tiles only) ------------------------------------------------------------
-    {
+    f32x4 acc[NTW > 0 ? NTW : 1];
+    if constexpr (NTW > 0) { // ---- first conv (this wave's tiles only)
+        float w0r[STEPS0];
+#pragma unroll
+        for (int s = 0; s < STEPS0; s++) w0r[s] = nd.w0[s * 64 + lane];
+        const f32x4 bias0 = *(const f32x4 *)(nd.epi + 4 * j), scale0 = *(const f32x4 *)(nd.epi + 16 + 4 * j),
+                    shift0 = *(const f32x4 *)(nd.epi + 32 + 4 * j);
 #pragma unroll
         for (int k = 0; k < NTW; k++) acc[k] = bias0;
 #pragma unroll
@@ -124,10 +112,7 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
             int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * CP + c;
             float a = w0r[s];
 #pragma unroll
-            for (int k = 0; k < NTW; k++) {
-                float b = inp[ioff[k] + toff];
-                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[k], 0, 0, 0);
-            }
+            for (int k = 0; k < NTW; k++) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, inp[ioff[k] + toff], acc[k], 0, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < NTW; k++) {
@@ -144,46 +129,94 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
     // layer l, which every wave finished reading before it reached the previous synchronisation) -----------
     const int L = (nd.dbg & 2) ? 0 : 2 * nd.R;
     for (int l = 0; l < L; l++) {
-        const float *in = (l & 1) ? actB : actA;
-        float *out = (l & 1) ? actA : actB;
-        const float *ep = nd.epi + (size_t)(1 + l) * 48;
-        f32x4 bias = *(const f32x4 *)(ep + 4 * j), scale = *(const f32x4 *)(ep + 16 + 4 * j),
-              shift = *(const f32x4 *)(ep + 32 + 4 * j);
-        f32x4 w[9];
+        if constexpr (NTW > 0) {
+            const float *in = (l & 1) ? actB : actA;
+            float *out = (l & 1) ? actA : actB;
+            const float *ep = nd.epi + (size_t)(1 + l) * 48;
+            f32x4 bias = *(const f32x4 *)(ep + 4 * j), scale = *(const f32x4 *)(ep + 16 + 4 * j),
+                  shift = *(const f32x4 *)(ep + 32 + 4 * j);
+            f32x4 w[9];
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) w[tap] = nd.wt[((size_t)l * 9 + tap) * 64 + lane];
+            for (int tap = 0; tap < 9; tap++) w[tap] = nd.wt[((size_t)l * 9 + tap) * 64 + lane];
 #pragma unroll
-        for (int k = 0; k < NTW; k++) acc[k] = bias;
+            for (int k = 0; k < NTW; k++) acc[k] = bias;
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * 4;
-            f32x4 b[NTW];
+            for (int tap = 0; tap < 9; tap++) {
+                const int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * 4;
+                f32x4 b[NTW];
 #pragma unroll
-            for (int k = 0; k < NTW; k++) b[k] = *(const f32x4 *)(in + aoff[k] + toff);
+                for (int k = 0; k < NTW; k++) b[k] = *(const f32x4 *)(in + aoff[k] + toff);
 #pragma unroll
-            for (int r = 0; r < 4; r++)
+                for (int r = 0; r < 4; r++)
 #pragma unroll
-                for (int k = 0; k < NTW; k++)
-                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][r], b[k][r], acc[k], 0, 0, 0);
-        }
-        const bool skip = (l & 1) != 0;
-#pragma unroll
-        for (int k = 0; k < NTW; k++) {
-            f32x4 y;
-            f32x4 sk = {0.f, 0.f, 0.f, 0.f};
-            if (skip) sk = *(const f32x4 *)(out + aoff[k]);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = __builtin_fmaf(acc[k][r], scale[r], shift[r]);
-                if (skip) v = v + sk[r];
-                y[r] = fmaxf(v, 0.f);
+                    for (int k = 0; k < NTW; k++)
+                        acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][r], b[k][r], acc[k], 0, 0, 0);
             }
-            if (valid[k]) *(f32x4 *)(out + aoff[k]) = y;
+            const bool skip = (l & 1) != 0;
+#pragma unroll
+            for (int k = 0; k < NTW; k++) {
+                f32x4 y;
+                f32x4 sk = {0.f, 0.f, 0.f, 0.f};
+                if (skip) sk = *(const f32x4 *)(out + aoff[k]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = __builtin_fmaf(acc[k][r], scale[r], shift[r]);
+                    if (skip) v = v + sk[r];
+                    y[r] = fmaxf(v, 0.f);
+                }
+                if (valid[k]) *(f32x4 *)(out + aoff[k]) = y;
+            }
         }
         TSTAMP(3);
         if (!team_sync<T>(tc, tw, epoch, qc, t_start, t_limit)) return false;
         TSTAMP(2);
     }
+    return true;
+}
+
+template <class G, int PW, int T>
+__device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int *slot_list, float *tl, TeamCtl *tc, int tw,
+                                              int &epoch, const typename G::State *states, const uint32_t *game_id,
+                                              const int32_t *serial, int noise, float *value_out, float *policy_out,
+                                              int pstride, QueueCtl *qc, long long t_start, long long t_limit TS_ARG) {
+    TS_INIT
+    static_assert(T == 4, "head roles and the tile deal are written for teams of four waves");
+    using NG = NetGeom<G, PW>;
+    constexpr int W = NG::W, CIN = NG::CIN, A = NG::A, HW = NG::HW, SLOTS = NG::SLOTS, CP = NG::CP, ACT = NG::ACT,
+                  PLANE = NG::PLANE;
+    const int lane = threadIdx.x & 63;
+    float *actA = tl;
+    float *actB = actA + ACT;
+    float *inp = actB + ACT;
+
+    // ---- prologue: every wave of the team stages the same boards and planes (identical stores, no sync needed)
+    {
+        const int my_pp = lane % PW;
+        const typename G::State my_state = states[slot_list[my_pp < n ? my_pp : 0]];
+        typename G::State *sst = (typename G::State *)(inp + PW * SLOTS * CP);
+        if (lane < PW) sst[lane] = my_state;
+        for (int q = lane; q < PW * HW; q += 64) {
+            int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
+            if (pp >= n) continue;
+            float *dst = inp + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * CP;
+            int8_t v[CIN];
+            G::encode_cell(sst[pp], y, x, v);
+#pragma unroll
+            for (int c = 0; c < CIN; c++) dst[c] = (float)v[c];
+        }
+    }
+    TSTAMP(0);
+    // ---- tower: tiles tw and tw+4 of the ceil(n*HW/16) tiles that hold real pixels
+    const int ntiles = (n * HW + 15) / 16;
+    const int mine = ntiles > tw + T ? 2 : (ntiles > tw ? 1 : 0);
+    bool ok;
+    if (mine == 2) ok = net_team_tower<G, PW, T, 2>(nd, n, tl, tc, tw, epoch, qc, t_start, t_limit TS_PASS);
+    else if (mine == 1) ok = net_team_tower<G, PW, T, 1>(nd, n, tl, tc, tw, epoch, qc, t_start, t_limit TS_PASS);
+    else ok = net_team_tower<G, PW, T, 0>(nd, n, tl, tc, tw, epoch, qc, t_start, t_limit TS_PASS);
+    if (!ok) return false;
+#ifdef BB_STAMPS
+    _ts = clock64();
+#endif
     // ---- heads: tower output is in actA; actB and inp are scratch.  One role per wave. ------------------------
     const float *hp = nd.head;
     const int D = nd.D;
@@ -194,7 +227,7 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
     float *nz = lg + PW * A;      // [PW][A]    Beta draws                  (wave 2 writes, wave 1 reads)
     if (tw == 0) {
         const float *vk = hp + nd.off_vk, *v3 = hp + nd.off_v3;
-        for (int q = lane; q < PW * HW; q += 64) {
+        for (int q = lane; q < n * HW; q += 64) {
             int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
             const float *xp = actA + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * 4;
             float av = v3[0];
@@ -207,14 +240,14 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
             rv[q] = fmaxf(__builtin_fmaf(av, v3[1], v3[2]), 0.f);
         }
         const float *d1k = hp + nd.off_d1k, *d1b = hp + nd.off_d1b;
-        for (int q = lane; q < PW * D; q += 64) {
+        for (int q = lane; q < n * D; q += 64) {
             int pp = q / D, dd = q % D;
             float s = 0.f, wk = d1k[dd], wb = d1b[dd];
 #pragma unroll
             for (int p = 0; p < HW; p++) s += __builtin_fmaf(rv[pp * HW + p], wk, wb);
             sd[q] = fmaxf(s, 0.f);
         }
-        if (lane < PW && lane < n) {
+        if (lane < n) {
             const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
             float e = d2b[0];
             for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(sd[lane * D + dd], d2k[dd], e);
@@ -224,7 +257,7 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
         for (int i = lane; i < PW * D; i += 64) sd[i] = 0.f;
     } else if (tw == 1) {
         const float *pk = hp + nd.off_pk, *p6 = hp + nd.off_p6;
-        for (int q = lane; q < PW * HW; q += 64) {
+        for (int q = lane; q < n * HW; q += 64) {
             int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
             const float *xp = actA + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * 4;
             float a0 = p6[0], a1 = p6[1];
@@ -242,7 +275,7 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
             rp[2 * q + 1] = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
         }
         const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
-        for (int q = lane; q < PW * A; q += 64) {
+        for (int q = lane; q < n * A; q += 64) {
             int pp = q / A, a = q % A;
             float s = 0.f, k0 = pdk[a], k1 = pdk[A + a], kb = pdb[a];
 #pragma unroll
@@ -250,20 +283,20 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
                 s += __builtin_fmaf(rp[2 * (pp * HW + p) + 1], k1, __builtin_fmaf(rp[2 * (pp * HW + p)], k0, kb));
             lg[q] = s;
         }
-    } else {
+    } else if (tw == 2) {
         if (noise) { // two lanes per (position, action): lane pair (2i, 2i+1) tries Philox pairs k and k+1 side by side
             const float ia = 1.0f / nd.alpha, ib = 1.0f / (1.0f - nd.alpha);
-            for (int base = 0; base < PW * A; base += 32) {
+            for (int base = 0; base < n * A; base += 32) {
                 int q = base + (lane >> 1), sub = lane & 1;
-                bool live = q < PW * A && q / A < n;
+                bool live = q < n * A;
                 int a = live ? q % A : 0;
-                int pos = live ? slot_list[q / A] : 0;
-                uint32_t gid = live ? game_id[pos] : 0u, ser = live ? (uint32_t)serial[pos] : 0u;
+                int pos = live ? slot_list[q / A] : slot_list[0];
+                uint32_t gid = game_id[pos], ser = (uint32_t)serial[pos];
                 float r = -1.0f;
                 for (uint32_t k = 0; k < 32 && __any(live && r < 0.0f); k += 2) {
-                    float mine = (live && r < 0.0f) ? bb_beta_pair(nd.seed, gid, ser, (uint32_t)a, ia, ib, k + sub) : -1.0f;
-                    float other = __shfl_xor(mine, 1, 64);
-                    float first = sub ? other : mine, second = sub ? mine : other; // pair k before pair k+1
+                    float mine_r = (live && r < 0.0f) ? bb_beta_pair(nd.seed, gid, ser, (uint32_t)a, ia, ib, k + sub) : -1.0f;
+                    float other = __shfl_xor(mine_r, 1, 64);
+                    float first = sub ? other : mine_r, second = sub ? mine_r : other; // pair k before pair k+1
                     if (r < 0.0f) r = first >= 0.0f ? first : second;
                 }
                 if (live && sub == 0) nz[q] = r >= 0.0f ? r : nd.alpha;
@@ -275,7 +308,7 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
     team_bump(tc, tw, epoch);
     if (tw == 1) {
         if (!team_wait(tc, 2, epoch, qc, t_start, t_limit)) return false;
-        if (lane < PW && lane < n) { // one lane finishes each position (sequential, oracle order)
+        if (lane < n) { // one lane finishes each position (sequential, oracle order)
             const int pp = lane, pos = slot_list[lane];
             float m = -INFINITY;
             for (int a = 0; a < A; a++) m = fmaxf(m, lg[pp * A + a]);
@@ -310,30 +343,20 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
     return true;
 }
 
-#ifdef BB_STAMPS
-#define TST tstamps[wave]
-#else
-#define TST nullptr
-#endif
-
 template <class G, int NTEAMS>
 __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev dg, NetDev nd, int visits, int noise_on, int limit_s) {
-    constexpr int S = G::S, GW = 16, T = 3, NETW = NTEAMS * T, TREEW = 12 - NETW, GPT = (GW + TREEW - 1) / TREEW, PWT = 2;
+    constexpr int S = G::S, GW = 16, T = 4, NETW = NTEAMS * T, TREEW = 12 - NETW, GPT = (GW + TREEW - 1) / TREEW, PWT = 3;
     static_assert(GPT * S <= 64, "a tree wave holds at most 64 / S games");
     using NG = NetGeom<G, PWT>;
-    using NG1 = NetGeom<G, 1>;
     constexpr int RMAX = MEGA_RMAX, STEPS0 = NG::STEPS0;
     constexpr int WT_F = 2 * RMAX * 9 * 64 * 4, W0_F = STEPS0 * 64, EPI_F = (1 + 2 * RMAX) * 48, HEAD_F = MEGA_HEAD_FLOATS;
-    // one region per batch size: the zero halo of one layout is interior in the other
     __shared__ __attribute__((aligned(16))) float lds[NTEAMS * NG::WAVE_FLOATS];
-    __shared__ __attribute__((aligned(16))) float lds1[NTEAMS * NG1::WAVE_FLOATS];
     __shared__ __attribute__((aligned(16))) float wlds[WT_F + W0_F + EPI_F + HEAD_F];
     __shared__ QueueCtl qc;
     __shared__ GameShadow<G, GW> shadow;
     __shared__ TeamCtl tcs[NTEAMS];
     __shared__ int gstate[GW]; // 0 owned by its tree wave, 1 leaf queued / being evaluated, 2 result published
 #ifdef BB_STAMPS
-    __shared__ long long ts_post[GW], ts_done[GW];
     __shared__ long long tstamps[12][8];
     if (threadIdx.x < 96) ((long long *)tstamps)[threadIdx.x] = 0;
 #endif
@@ -352,7 +375,6 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev dg, Net
     if (threadIdx.x < MEGA2_QCAP) qc.q[threadIdx.x] = -1;
     for (int i = threadIdx.x; i < NTEAMS * (int)(sizeof(TeamCtl) / 4); i += MEGA2_THREADS) ((int *)tcs)[i] = 0;
     for (int i = threadIdx.x; i < NTEAMS * NG::WAVE_FLOATS; i += MEGA2_THREADS) lds[i] = 0.f;
-    for (int i = threadIdx.x; i < NTEAMS * NG1::WAVE_FLOATS; i += MEGA2_THREADS) lds1[i] = 0.f;
     NetDev ndl = nd;
     {
         const float *gwt = (const float *)nd.wt;
@@ -376,9 +398,6 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev dg, Net
         const bool mine = l64 < GPT * S && li < GW && g0 + li < d.n_slots;
         const int g = g0 + li;
         int left = mine ? visits : 0;
-#ifdef BB_STAMPS
-        long long t_work = 0, t_all0 = clock64(), n_calls = 0, n_lanes = 0, t_pick = 0, n_pick = 0;
-#endif
         for (;;) {
             int stt = mine ? lds_load(&gstate[li]) : 1;
             bool ready = mine && left > 0 && stt != 1;
@@ -387,27 +406,12 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev dg, Net
             if (__any(ready)) {
                 __threadfence_block(); // acquire: the network team's results for state 2
                 bool posted = false;
-#ifdef BB_STAMPS
-                long long ts = clock64();
-                n_calls++;
-                n_lanes += __popcll(__ballot(ready)) / S;
-                if (ready && lane == 0 && stt == 2) {
-                    t_pick += wall_clock64() - ts_done[li];
-                    n_pick++;
-                }
-#endif
                 if (ready) {
                     posted = async_game<G>(d, g, lane);
                     left--;
                     if (d.game_lid[g] < 0) left = 0; // slot ran out of games
                 }
-#ifdef BB_STAMPS
-                if (ready && lane == 0 && posted) ts_post[li] = wall_clock64();
-#endif
                 queue_push(&qc, &gstate[li < GW ? li : 0], ready && lane == 0, posted, li);
-#ifdef BB_STAMPS
-                t_work += clock64() - ts;
-#endif
             } else {
                 __builtin_amdgcn_s_sleep(4);
                 int late = wall_clock64() - t_start > t_limit || lds_load(&qc.abort_flag);
@@ -418,37 +422,31 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev dg, Net
             }
         }
         if (l64 == 0) atomicAdd(&qc.tree_done, 1);
-#ifdef BB_STAMPS
-        if (l64 == 0 && d.stamps) {
-            atomicAdd(&d.stamps[2], (unsigned long long)t_work);
-            atomicAdd(&d.stamps[3], (unsigned long long)(clock64() - t_all0));
-            atomicAdd(&d.stamps[5], 1ull);
-            atomicAdd(&d.stamps[13], (unsigned long long)n_calls);
-            atomicAdd(&d.stamps[14], (unsigned long long)n_lanes);
-        }
-        if (lane == 0 && d.stamps && n_pick) {
-            atomicAdd(&d.stamps[8], (unsigned long long)t_pick);
-            atomicAdd(&d.stamps[9], (unsigned long long)n_pick);
-        }
-#endif
     } else { // ---------------- network teams ----------------
         const int team = wave / T, tw = wave % T;
         TeamCtl *tc = &tcs[team];
-        float *tl = lds + team * NG::WAVE_FLOATS, *tl1 = lds1 + team * NG1::WAVE_FLOATS;
+        float *tl = lds + team * NG::WAVE_FLOATS;
         int epoch = 0;
 #ifdef BB_STAMPS
-        long long t_work = 0, t_all0 = clock64(), n_evals = 0, t_qwait = 0, n_pairs = 0;
+        long long t_work = 0, t_all0 = clock64(), n_evals = 0, n_pass = 0;
 #endif
         for (;;) {
-            if (tw == 0) { // the team leader takes one or two queued leaves and tells the others
-                int a = __builtin_amdgcn_readfirstlane(queue_pop(&qc, t_start, t_limit, TREEW));
-                int b = -1;
-                if (a >= 0) b = __builtin_amdgcn_readfirstlane(queue_pop(&qc, t_start, t_limit, TREEW));
-                *(volatile int *)&tc->li[0] = a;
-                *(volatile int *)&tc->slot[0] = g0 + (a >= 0 ? a : 0);
-                *(volatile int *)&tc->li[1] = b;
-                *(volatile int *)&tc->slot[1] = g0 + (b >= 0 ? b : 0);
-                *(volatile int *)&tc->n = a < 0 ? a : (b >= 0 ? 2 : 1);
+            if (tw == 0) { // the team leader takes up to PWT queued leaves and tells the others
+                int got[PWT];
+                int cnt = 0, first = -1;
+#pragma unroll
+                for (int k = 0; k < PWT; k++) {
+                    int a = (k == 0 || cnt == k) ? __builtin_amdgcn_readfirstlane(queue_pop(&qc, t_start, t_limit, TREEW)) : -1;
+                    if (k == 0) first = a;
+                    got[k] = a;
+                    if (a >= 0) cnt++;
+                }
+#pragma unroll
+                for (int k = 0; k < PWT; k++) {
+                    *(volatile int *)&tc->li[k] = got[k];
+                    *(volatile int *)&tc->slot[k] = g0 + (got[k] >= 0 ? got[k] : 0);
+                }
+                *(volatile int *)&tc->n = cnt > 0 ? cnt : first; // first is -1 (nothing queued) or -2 (finished)
             }
             if (!team_sync<T>(tc, tw, epoch, &qc, t_start, t_limit)) break;
             const int n = __builtin_amdgcn_readfirstlane(*(volatile int *)&tc->n);
@@ -462,19 +460,15 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev dg, Net
 #ifdef BB_STAMPS
             long long ts = clock64();
             n_evals += n;
-            n_pairs += n == 2;
-            t_qwait += wall_clock64() - ts_post[tc->li[0]];
-            if (n == 2) t_qwait += wall_clock64() - ts_post[tc->li[1]];
+            n_pass++;
 #endif
-            bool ok;
-            if (n == 2)
-                ok = net_team_body<G, 2, T>(ndl, 2, tc->slot, tl, tc, tw, epoch, (const typename G::State *)d.leaf_state,
-                                            d.leaf_game_id, d.leaf_serial, noise_on, d.eval_value, d.eval_policy, S, &qc,
-                                            t_start, t_limit, TST);
-            else
-                ok = net_team_body<G, 1, T>(ndl, 1, tc->slot, tl1, tc, tw, epoch, (const typename G::State *)d.leaf_state,
-                                            d.leaf_game_id, d.leaf_serial, noise_on, d.eval_value, d.eval_policy, S, &qc,
-                                            t_start, t_limit, TST);
+            bool ok = net_team_body<G, PWT, T>(ndl, n, tc->slot, tl, tc, tw, epoch, (const typename G::State *)d.leaf_state,
+                                               d.leaf_game_id, d.leaf_serial, noise_on, d.eval_value, d.eval_policy, S, &qc,
+                                               t_start, t_limit
+#ifdef BB_STAMPS
+                                               , tstamps[wave]
+#endif
+                                               );
             if (!ok) break;
             // everybody waits for everybody: the results are published, and the leader may reuse the control block
             bool fine = true;
@@ -482,22 +476,16 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev dg, Net
             for (int k = 0; k < T; k++)
                 if (k != tw && !team_wait(tc, k, epoch, &qc, t_start, t_limit)) fine = false;
             if (!fine) break;
+            if (tw == 0)
+                for (int k = 0; k < n; k++) *(volatile int *)&gstate[tc->li[k]] = 2;
 #ifdef BB_STAMPS
-            if (tw == 0) {
-                ts_done[tc->li[0]] = wall_clock64();
-                if (n == 2) ts_done[tc->li[1]] = wall_clock64();
-            }
             t_work += clock64() - ts;
 #endif
-            if (tw == 0) {
-                *(volatile int *)&gstate[tc->li[0]] = 2;
-                if (n == 2) *(volatile int *)&gstate[tc->li[1]] = 2;
-            }
         }
 #ifdef BB_STAMPS
         if (l64 == 0) {
             for (int i = 0; i < 4; i++) atomicAdd(&g_net_stamps[i], (unsigned long long)tstamps[wave][i]);
-            atomicAdd(&g_net_stamps[4 + tw], (unsigned long long)tstamps[wave][4]); // head time per role
+            atomicAdd(&g_net_stamps[4 + (tw < 3 ? tw : 2)], (unsigned long long)tstamps[wave][4]); // head time per role
             atomicAdd(&g_net_stamps[7], (unsigned long long)tstamps[wave][5]);
         }
         if (tw == 0 && l64 == 0 && d.stamps) {
@@ -505,16 +493,10 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev dg, Net
             atomicAdd(&d.stamps[1], (unsigned long long)(clock64() - t_all0));
             atomicAdd(&d.stamps[4], 1ull);
             atomicAdd(&d.stamps[15], (unsigned long long)n_evals);
-            atomicAdd(&d.stamps[10], (unsigned long long)t_qwait);
-            atomicAdd(&d.stamps[11], (unsigned long long)n_pairs);
+            atomicAdd(&d.stamps[11], (unsigned long long)n_pass);
         }
 #endif
     }
-#ifdef BB_STAMPS
-    if (wave < NETW && wave % T == 0 && l64 == 0 && d.stamps) {
-        // (t_work etc. are in scope only in the team branch: flushed there)
-    }
-#endif
     __syncthreads();
     if (threadIdx.x == 0 && qc.abort_flag) d.ctr[(size_t)g0 * 8 + 6] += 1; // surfaces as bb_counters.overflow
     __syncthreads();

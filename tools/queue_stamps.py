@@ -28,7 +28,8 @@ clk = 2.4e3  # shader cycles per us (approx); wall clock ticks are 100 MHz
 print(f"per evaluation: queue wait {st[10]/st[15]/100:.1f} us, network {st[0]/st[15]/clk:.1f} us; result pick-up wait {st[8]/max(st[9],1)/100:.1f} us; tree call {st[2]/st[13]/clk:.1f} us")
 L.bb_debug_net_stamps(eng.h, ns.ctypes.data); ns = ns.astype(np.float64)
 if os.environ.get("QMODE") == "2":
-    passes = st[15] - st[11]  # evaluations - pairs = team passes
+    passes = st[11]
     ns = ns / passes
-    print("team pass, cycles (mean over the 3 waves where summed): prologue %.0f, first conv %.0f, layer compute %.0f, sync waits %.0f | heads: value wave %.0f, policy wave %.0f, noise wave %.0f | mix+store %.0f"
-          % (ns[0] / 3, ns[1] / 3, ns[3] / 3, ns[2] / 3, ns[4], ns[5], ns[6], ns[7] / 3))
+    print("team passes %.0f, positions per pass %.2f, cycles per pass %.0f" % (passes, st[15] / passes, st[0] / passes))
+    print("per pass, cycles (mean over the 4 waves where summed): prologue %.0f, first conv %.0f, layer compute %.0f, sync waits %.0f | heads: value wave %.0f, policy wave %.0f, noise+idle waves %.0f | mix+store %.0f"
+          % (ns[0] / 4, ns[1] / 4, ns[3] / 4, ns[2] / 4, ns[4], ns[5], ns[6], ns[7] / 4))
