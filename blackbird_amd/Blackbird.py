@@ -128,6 +128,12 @@ def TestModels(model1, model2, temp, numTests):
             return -1
 
 
+def TestModelsBatched(model1, model2, temp, numTests, **kw):
+    """All `numTests` games of TestModels at once on the GPU (blackbird_amd/arena.py); returns an array of +1/0/-1."""
+    from .arena import TestModelsBatched as run
+    return run(model1, model2, temp, numTests, **kw)
+
+
 def _tally(model, opponent, temp, numTests, opName, opVersion=0):
     resultMap = {1: 'wins', 0: 'draws', -1: 'losses'}
     stats = defaultdict(int)

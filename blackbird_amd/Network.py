@@ -22,8 +22,10 @@ class Network:
         self._weights = None
         self._eval_engine = None
         self._trainer = None
-        self.alpha = getattr(networkConstructor, 'alpha', 0.2) or 0.2
-        self.epsilon = getattr(networkConstructor, 'epsilon', 0.3) or 0.3
+        alpha = getattr(networkConstructor, 'alpha', None)
+        epsilon = getattr(networkConstructor, 'epsilon', None)
+        self.alpha = 0.2 if alpha is None else alpha          # (an explicit epsilon of 0 switches the noise off)
+        self.epsilon = 0.3 if epsilon is None else epsilon
         if not self.loadModel(name):
             if networkConstructor is not None and getattr(networkConstructor, 'inputShape', None):
                 self._weights = networkConstructor()

@@ -20,7 +20,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_NAN, ERR_CAPACITY, ERR_WEIGHTS = 0, -1, -2,
 EXPORTS = (
     "bb_game_info_get", "bb_last_error", "bb_device_count", "bb_game_legal", "bb_game_apply", "bb_game_winner",
     "bb_game_encode", "bb_game_initial", "bb_create", "bb_destroy", "bb_load_weights", "bb_get_counters",
-    "bb_reset_counters", "bb_synchronize", "bb_set_sims_per_move", "bb_timing_enable", "bb_timing_read", "bb_timing_net", "bb_selfplay_mode", "bb_net_eval", "bb_hash_eval", "bb_set_roots", "bb_run_sims",
+    "bb_reset_counters", "bb_synchronize", "bb_set_sims_per_move", "bb_timing_enable", "bb_timing_read", "bb_timing_net", "bb_selfplay_mode", "bb_net_eval", "bb_hash_eval", "bb_set_roots", "bb_run_sims", "bb_run_sims_masked",
     "bb_sample_moves", "bb_move_roots", "bb_get_root_states", "bb_selfplay_begin", "bb_selfplay_step",
     "bb_selfplay_done", "bb_examples_fetch", "bb_examples_device",
 )
@@ -93,6 +93,7 @@ def lib():
     L.bb_hash_eval.argtypes = [vp, ip, vp, vp, vp]
     L.bb_set_roots.argtypes = [vp, ip, vp, vp, vp]
     L.bb_run_sims.argtypes = [vp, ip]
+    L.bb_run_sims_masked.argtypes = [vp, ip, vp]
     L.bb_sample_moves.argtypes = [vp, C.c_double, vp, vp, vp, vp, vp, vp, vp]
     L.bb_move_roots.argtypes = [vp, vp]
     L.bb_get_root_states.argtypes = [vp, vp]
@@ -356,8 +357,13 @@ class Engine:
         gids = None if game_ids is None else np.ascontiguousarray(game_ids, dtype=np.uint32)
         check(lib().bb_set_roots(self.h, n, ptr(slots), ptr(states), ptr(gids)))
 
-    def run_sims(self, sims):
-        check(lib().bb_run_sims(self.h, int(sims)))
+    def run_sims(self, sims, mask=None):
+        if mask is None:
+            check(lib().bb_run_sims(self.h, int(sims)))
+        else:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert mask.shape[0] == self.n_slots
+            check(lib().bb_run_sims_masked(self.h, int(sims), ptr(mask)))
 
     def sample_moves(self, temp, u=None):
         n, S = self.n_slots, self.info.S

@@ -816,13 +816,18 @@ extern "C" int bb_set_roots(bb_engine *e, int n, const int32_t *slots, const voi
     GAME_SWITCH(e->cfg.game, return set_roots<G>(e, n, slots, states, game_ids));
 }
 
-extern "C" int bb_run_sims(bb_engine *e, int sims) {
+static int run_sims_api(bb_engine *e, int sims, const uint8_t *mask) {
     if (!e || sims <= 0) return fail(BB_ERR_ARG, "Not enough information to decide a stop time."); // MCTS.py:181-182
     int rc = check_eval(e);
     if (rc) return rc;
     HIPCHK(hipSetDevice(e->cfg.device));
+    DevBuf dm;
+    if (mask) {
+        if (dm.alloc((size_t)e->dev.n_slots)) return BB_ERR_HIP;
+        HIPCHK(hipMemcpyAsync(dm.p, mask, (size_t)e->dev.n_slots, hipMemcpyDefault, e->stream));
+    }
     GAME_SWITCH(e->cfg.game, {
-        k_add_sims<typename std::conditional<G::GID == BB_GAME_DRAGONCHESS, Connect4, G>::type><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, sims);
+        k_add_sims<typename std::conditional<G::GID == BB_GAME_DRAGONCHESS, Connect4, G>::type><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev, sims, mask ? (const uint8_t *)dm.p : nullptr);
         rc = run_sims<G>(e, sims);
         if (rc) return rc;
         if constexpr (G::GID == BB_GAME_DRAGONCHESS)
@@ -830,8 +835,16 @@ extern "C" int bb_run_sims(bb_engine *e, int sims) {
         else
             k_tree_apply<G><<<nblk((size_t)e->dev.n_slots * G::S), 256, 0, e->stream>>>(e->dev);
         HIPCHK(hipGetLastError());
+        if (mask) HIPCHK(sync_all(e)); // the mask buffer is freed on return
         return BB_OK;
     });
+}
+
+extern "C" int bb_run_sims(bb_engine *e, int sims) { return run_sims_api(e, sims, nullptr); }
+
+extern "C" int bb_run_sims_masked(bb_engine *e, int sims, const uint8_t *mask) {
+    if (!mask) return fail(BB_ERR_ARG, "null mask");
+    return run_sims_api(e, sims, mask);
 }
 
 template <class G>

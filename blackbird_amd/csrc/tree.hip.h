@@ -661,10 +661,10 @@ __global__ void __launch_bounds__(256) k_set_roots(TreeDev d, int n, const int32
 }
 
 template <class G>
-__global__ void __launch_bounds__(256) k_add_sims(TreeDev d, int sims) {
+__global__ void __launch_bounds__(256) k_add_sims(TreeDev d, int sims, const uint8_t *mask = nullptr) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.n_slots) return;
-    if (d.game_lid[g] >= 0) d.sims_left[g] = sims;
+    if (d.game_lid[g] >= 0 && (!mask || mask[g])) d.sims_left[g] = sims; // (slots outside the mask keep their trees untouched)
 }
 
 template <class G>

@@ -185,6 +185,10 @@ int bb_set_roots(bb_engine *e, int n, const int32_t *slots, const void *states, 
 /* _runMCTS (MCTS.py:284-303): `sims` more simulations on every active slot, playLimit semantics
  * (added to Root.Plays). */
 int bb_run_sims(bb_engine *e, int sims);
+/* The same for the slots with mask[slot] != 0 only (mask[n_slots], host memory); the other slots' trees are left
+ * untouched.  This is what a batched arena needs (Blackbird.py:177-216, TestModels: two searchers share the games and
+ * each one only searches the positions where it is to move). */
+int bb_run_sims_masked(bb_engine *e, int sims, const uint8_t *mask);
 /* After bb_run_sims: Root statistics + the move _selectAction(exploring=False) picks (MCTS.py:335-338).
  * u[n_slots] uniforms in [0,1) for np.random.choice's law, or NULL to draw Philox(seed, game_id, ply).
  * Outputs per slot (S = bb_game_info.S): action (or BB_ERR_NAN), root_winrate = Root.WinRate(),
