@@ -109,13 +109,19 @@ def test_tree_with_net_matches_oracle_tree_on_gpu_values(orc):
     _selfplay_vs_oracle_tree(orc, filters=16, blocks=4)
 
 
-def _selfplay_vs_oracle_tree(orc, filters, blocks):
-    game, og = _lib.GAME_CONNECT4, 0
+@pytest.mark.parametrize("game,og,n_slots,n_games,max_plies", [(_lib.GAME_TICTACTOE, 1, 21, 50, 10), (_lib.GAME_CONNECT4, 0, 19, 45, 43)])
+def test_persistent_kernel_ragged_slots_and_slot_reuse(orc, game, og, n_slots, n_games, max_plies):
+    """The default persistent kernel with a slot count that is not a multiple of its 16-game workgroups and more games
+    than slots (every slot plays several games): still the oracle's search, game by game."""
+    _selfplay_vs_oracle_tree(orc, filters=16, blocks=2, game=game, og=og, n_slots=n_slots, n_games=n_games, sims=24,
+                             max_plies=max_plies)
+
+
+def _selfplay_vs_oracle_tree(orc, filters, blocks, game=_lib.GAME_CONNECT4, og=0, n_slots=8, n_games=6, sims=40, max_plies=43):
     gi = _lib.game_info(game)
     w = W.init_weights(gi.C, filters, blocks, 16, gi.A, seed=21)
     flat = W.flatten(w)
-    n_games, sims = 6, 40
-    eng = _lib.Engine(game, n_slots=8, sims_per_move=sims, evaluator=_lib.EVAL_NET, seed=17, max_games=n_games)
+    eng = _lib.Engine(game, n_slots=n_slots, sims_per_move=sims, evaluator=_lib.EVAL_NET, seed=17, max_games=n_games)
     eng.load_weights(flat)
     eng.selfplay_begin(n_games, 1.0)
     while not eng.selfplay_done()[0]:
@@ -134,10 +140,10 @@ def _selfplay_vs_oracle_tree(orc, filters, blocks):
 
     cfg = orc.make_cfg(og, evaluator=orc.EVAL_CALLBACK, seed=17, cb=orc.EVAL_CB(cb))
     for gidx in range(n_games):
-        o = orc.selfplay_game(cfg, gidx, 1.0, sims, 42)
+        o = orc.selfplay_game(cfg, gidx, 1.0, sims, max_plies - 1)
         r = rec[offs[gidx]:offs[gidx + 1]]
         assert len(r) == o["n"] and win[gidx] == o["winner"], gidx
         tot = np.maximum(r["total"].astype(np.float64), 1.0)[:, None]
-        assert np.array_equal(r["visits"][:, :7] / tot, o["pi"]), gidx
+        assert np.array_equal(r["visits"][:, :gi.A] / tot, o["pi"]), gidx
     eng.close()
     ev.close()
