@@ -982,9 +982,15 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
         return fail(BB_ERR_ARG, "asynchronous self-play is for the dense-action games");
     } else {
         constexpr int PWMAX = NetPW<G>::v;
-        if (e->mega && !e->general_net && e->net.R <= MEGA_RMAX && e->net.head_floats <= MEGA_HEAD_FLOATS) { // one persistent launch: `rounds` visits of every game == 2*rounds phases
+        if (e->mega && !e->general_net && e->net.R <= MEGA_RMAX && e->net.head_floats <= MEGA_HEAD_FLOATS) {
+            // persistent launches of at most 16 plies' worth of visits each: every spin loop inside is bounded by
+            // BB_QUEUE_LIMIT_S of wall clock, so one launch must stay far below it whatever the caller asks for
             TreeDev &d = e->dev;
             int nb = (d.n_slots + 15) / 16;
+            const int per_launch = 16 * (e->sims_now > 0 ? e->sims_now : 1);
+            const int all_rounds = rounds;
+          for (int done_rounds = 0; done_rounds < all_rounds; done_rounds += per_launch) {
+            rounds = all_rounds - done_rounds < per_launch ? all_rounds - done_rounds : per_launch;
             bool timed = e->time_every > 0 && e->ev_used + 2 <= e->ev_pool.size();
             if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
             TreeDev dm = d;
@@ -1015,6 +1021,7 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
                 HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
                 e->ev_used += 2;
             }
+          }
             return BB_OK;
         }
         for (int r = 0; r < rounds; r++) {
