@@ -1003,7 +1003,6 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
                     k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
             } else if (e->mega_queue) {
                 int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
-                lim = (lim & 255) | (int)((getenv("BB_SHADOW_MASK") ? (unsigned)strtoul(getenv("BB_SHADOW_MASK"), nullptr, 0) : 0x3fffffu) << 8);
                 int netw = getenv("BB_QUEUE_NETW") ? atoi(getenv("BB_QUEUE_NETW")) : 8;
                 if constexpr (G::S == 8) {
                     if (netw == 6) k_selfplay_queue<G, 6><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
@@ -1201,14 +1200,6 @@ extern "C" int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, dou
 }
 
 
-#if defined(BB_STAMPS) || defined(BB_DEBUG_API)
-extern "C" int bb_debug_slot_i32(bb_engine *e, int which, int32_t *out) {
-    HIPCHK(sync_all(e));
-    const int32_t *src[] = {e->dev.sims_left, e->dev.game_lid, e->dev.ply, e->dev.root_N, e->dev.pend_leaf, e->dev.n_nodes, e->dev.root, e->dev.resume_cur, e->dev.sim_serial, e->dev.path_len};
-    HIPCHK(hipMemcpy(out, src[which], (size_t)e->dev.n_slots * 4, hipMemcpyDeviceToHost));
-    return BB_OK;
-}
-#endif
 #ifdef BB_STAMPS
 // diagnostic builds only: point the stamp buffer at host-coherent memory so that it can be read while a kernel runs
 extern "C" int bb_debug_host_stamps(bb_engine *e, unsigned long long **host_out) {

@@ -25,11 +25,6 @@ __device__ __forceinline__ void release_global_then_lds() {
     __threadfence_block();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-#ifdef BB_QMARK
-#define QMARK(v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && d.stamps) __hip_atomic_store(&d.stamps[threadIdx.x >> 6], (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
-#else
-#define QMARK(v) do {} while (0)
-#endif
 
 
 // ---- per-game control state shadowed in LDS for the lifetime of the launch ----------------------------------
@@ -70,22 +65,20 @@ struct GameShadow {
 #undef X
         for (int i = threadIdx.x; i < n; i += nthreads) leaf_state[i] = ((const typename G::State *)d.leaf_state)[g0 + i];
     }
-    __device__ __forceinline__ void store(const TreeDev &d, int g0, int n, int nthreads, unsigned mask = ~0u) {
-        int k = 0;
-#define X(f, per) if ((mask >> k++) & 1u) for (int i = threadIdx.x; i < n * (per); i += nthreads) d.f[(size_t)g0 * (per) + i] = f[i];
+    __device__ __forceinline__ void store(const TreeDev &d, int g0, int n, int nthreads) {
+#define X(f, per) for (int i = threadIdx.x; i < n * (per); i += nthreads) d.f[(size_t)g0 * (per) + i] = f[i];
         BB_SHADOW_ARRAYS(X)
 #undef X
-        if ((mask >> k) & 1u) for (int i = threadIdx.x; i < n; i += nthreads) ((typename G::State *)d.leaf_state)[g0 + i] = leaf_state[i];
+        for (int i = threadIdx.x; i < n; i += nthreads) ((typename G::State *)d.leaf_state)[g0 + i] = leaf_state[i];
     }
-    __device__ __forceinline__ TreeDev rebased(const TreeDev &d, int g0, unsigned mask = ~0u) {
+    __device__ __forceinline__ TreeDev rebased(const TreeDev &d, int g0) {
         TreeDev r = d;
-        int k = 0;
         // (integer arithmetic on the generic address: `array - g0` as pointer arithmetic is out of bounds, and the
         // compiler folds it into 32-bit LDS-offset arithmetic that wraps)
-#define X(f, per) if ((mask >> k++) & 1u) r.f = (decltype(r.f))(generic_addr(f) - (unsigned long long)g0 * (per) * sizeof(f[0]));
+#define X(f, per) r.f = (decltype(r.f))(generic_addr(f) - (unsigned long long)g0 * (per) * sizeof(f[0]));
         BB_SHADOW_ARRAYS(X)
 #undef X
-        if ((mask >> k) & 1u) r.leaf_state = (void *)(generic_addr(leaf_state) - (unsigned long long)g0 * sizeof(leaf_state[0]));
+        r.leaf_state = (void *)(generic_addr(leaf_state) - (unsigned long long)g0 * sizeof(leaf_state[0]));
         return r;
     }
 };
@@ -157,9 +150,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
     const int g0 = blockIdx.x * GW;
     const int n_mine = dg.n_slots - g0 < GW ? dg.n_slots - g0 : GW;
     shadow.load(dg, g0, n_mine, MEGA2_THREADS);
-    const unsigned smask = (unsigned)limit_s >> 8;
-    const TreeDev d = shadow.rebased(dg, g0, smask); // everything below works on the LDS copies
-    limit_s &= 255;
+    const TreeDev d = shadow.rebased(dg, g0); // everything below works on the LDS copies
     if (threadIdx.x == 0) {
         qc.head = 0;
         qc.tail = 0;
@@ -182,7 +173,6 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
         ndl.head = wlds + WT_F + W0_F + EPI_F;
     }
     __syncthreads();
-    QMARK(1);
     const long long t_start = wall_clock64();
     const long long t_limit = 100000000ll * limit_s; // wall clock runs at 100 MHz
 
@@ -206,7 +196,6 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
             if (__any(ready)) {
                 __threadfence_block(); // acquire: the network wave's results for state 2
                 bool posted = false;
-                QMARK(3);
 #ifdef BB_STAMPS
                 long long ts = clock64();
                 n_calls++;
@@ -221,7 +210,6 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
                     left--;
                     if (d.game_lid[g] < 0) left = 0; // slot ran out of games
                 }
-                QMARK(4);
 #ifdef BB_STAMPS
                 if (ready && lane == 0 && posted) ts_post[li] = wall_clock64();
 #endif
@@ -230,7 +218,6 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
                 t_work += clock64() - ts;
 #endif
             } else {
-                QMARK(2);
                 __builtin_amdgcn_s_sleep(4);
                 int late = wall_clock64() - t_start > t_limit || lds_load(&qc.abort_flag);
                 if (__builtin_amdgcn_readfirstlane(late)) {
@@ -239,7 +226,6 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
                 }
             }
         }
-        QMARK(7);
         if (l64 == 0) atomicAdd(&qc.tree_done, 1);
 #ifdef BB_STAMPS
         if (l64 == 0 && d.stamps) {
@@ -263,12 +249,10 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
             const int li = __builtin_amdgcn_readfirstlane(queue_pop(&qc, t_start, t_limit, TREEW)); // scalar: uniform branches below
             if (li == -2) break;
             if (li < 0) {
-                QMARK(20);
                 __builtin_amdgcn_s_sleep(4);
                 continue;
             }
             __threadfence_block(); // acquire: the tree wave's mailbox writes
-            QMARK(5);
 #ifdef BB_STAMPS
             long long ts = clock64();
             n_evals++;
@@ -288,7 +272,6 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
                            d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false, d.eval_noise);
 #endif
             release_global_then_lds(); // value / policy before the state word
-            QMARK(6);
 #ifdef BB_STAMPS
             if (l64 == 0) ts_done[li] = wall_clock64();
 #endif
@@ -307,10 +290,8 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
         }
 #endif
     }
-    QMARK(8);
     __syncthreads();
-    QMARK(9);
     if (threadIdx.x == 0 && qc.abort_flag) d.ctr[(size_t)g0 * 8 + 6] += 1; // surfaces as bb_counters.overflow
     __syncthreads();
-    shadow.store(dg, g0, n_mine, MEGA2_THREADS, smask); // hand the per-game state back to HBM
+    shadow.store(dg, g0, n_mine, MEGA2_THREADS); // hand the per-game state back to HBM
 }
