@@ -120,25 +120,38 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
                 R0 += rp[2 * (pp * HW + p)];
                 R1 += rp[2 * (pp * HW + p) + 1];
             }
+            // the (A+63)/64 logits of a lane stay in registers from the GEMV to the normalised store: one pass over the
+            // head weights (L2-resident, shared by all positions) and ONE 16 KB write per position, instead of three
+            // writes and two re-reads of the policy row
+            constexpr int NPL = (A + 63) / 64;
+            float sv[NPL];
             float m = -INFINITY;
-            for (int a = lane; a < A; a += 64) {
-                float s = __builtin_fmaf(R1, pdk[A + a], __builtin_fmaf(R0, pdk[a], (float)HW * pdb[a]));
-                if (logits_out) logits_out[(size_t)pos * A + a] = s;
-                if (outp) outp[a] = s;
-                m = fmaxf(m, s);
+#pragma unroll
+            for (int k = 0; k < NPL; k++) {
+                const int a = lane + 64 * k;
+                if (a < A) {
+                    sv[k] = __builtin_fmaf(R1, pdk[A + a], __builtin_fmaf(R0, pdk[a], (float)HW * pdb[a]));
+                    if (logits_out) logits_out[(size_t)pos * A + a] = sv[k];
+                    m = fmaxf(m, sv[k]);
+                } else {
+                    sv[k] = -INFINITY;
+                }
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-            float tot = 0.f;
             if (outp) {
-                for (int a = lane; a < A; a += 64) {
-                    float e = expf(outp[a] - m);
-                    outp[a] = e;
-                    tot += e;
-                }
+                float tot = 0.f;
+#pragma unroll
+                for (int k = 0; k < NPL; k++)
+                    if (lane + 64 * k < A) {
+                        sv[k] = expf(sv[k] - m);
+                        tot += sv[k];
+                    }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-                for (int a = lane; a < A; a += 64) outp[a] = outp[a] / tot;
+#pragma unroll
+                for (int k = 0; k < NPL; k++)
+                    if (lane + 64 * k < A) outp[lane + 64 * k] = sv[k] / tot;
             }
             if (lane == 0 && value_out) {
                 float e = d2b[0];
