@@ -112,8 +112,9 @@ __global__ void __launch_bounds__(256) k_rollout(int n, const typename G::State 
 __global__ void __launch_bounds__(256) k_dc_legal(int n, const DCState *st, uint8_t *out) {
     int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (w >= n) return;
-    DCState s = st[w];
-    uint64_t m = DragonChess::targets(s, lane);
+    const int piece = st[w].b[lane];
+    const uint64_t white = __ballot(piece > 0), black = __ballot(piece < 0);
+    uint64_t m = DragonChess::targets_bits(piece, st[w].player, lane, white, black);
     uint8_t *o = out + (size_t)w * 4032 + lane * 63;
     for (int sq2 = 0, k = 0; sq2 < 64; sq2++) {
         if (sq2 == lane) continue;

@@ -284,14 +284,78 @@ struct DragonChess {
     }
 
     // legal targets of one from-square as a 64-bit mask (bit = to-square)
-    BB_HD static uint64_t targets(const State &s, int sq1) {
+    // b may point at a copy of the board in LDS: the 63 legality tests index the board dynamically, which on a
+    // register-resident State means scratch-memory round trips
+    BB_HD static uint64_t targets_from(const int8_t *b, int player, int sq1) {
         uint64_t m = 0;
-        int piece = s.b[sq1];
-        if (piece == 0 || (piece < 0 && s.player == 1) || (piece > 0 && s.player == 2)) return 0;
+        int piece = b[sq1];
+        if (piece == 0 || (piece < 0 && player == 1) || (piece > 0 && player == 2)) return 0;
         for (int sq2 = 0; sq2 < 64; sq2++)
-            if (sq2 != sq1 && is_legal(s.b, s.player, sq1 >> 3, sq1 & 7, sq2 >> 3, sq2 & 7)) m |= 1ull << sq2;
+            if (sq2 != sq1 && is_legal(b, player, sq1 >> 3, sq1 & 7, sq2 >> 3, sq2 & 7)) m |= 1ull << sq2;
         return m;
     }
+    BB_HD static uint64_t targets(const State &s, int sq1) { return targets_from(s.b, s.player, sq1); }
+    // The same legality rules (DragonChess.py:225-363 via is_legal above) as bit operations for one from-square, given
+    // the board's occupancy: `white` / `black` = squares holding a positive / negative piece.  A wave whose lane i holds
+    // square i gets the three masks from two ballots.  Sliders walk their rays until the first occupied square (own:
+    // stop before it, enemy: capture it); king / knight by offsets; pawns follow the reference's literal rules (no
+    // promotion, no en passant, double step from the start row only over two empty squares, a pawn that would promote
+    // has no move, captures one row ahead from any row that has one).  Checked against is_legal on the reference's
+    // golden boards, which include unreachable positions (tests/test_gpu_games.py).
+    BB_HD static uint64_t targets_bits(int piece, int player, int sq1, uint64_t white, uint64_t black) {
+        if (piece == 0 || (piece < 0 && player == 1) || (piece > 0 && player == 2)) return 0;
+        const uint64_t occ = white | black, own = piece > 0 ? white : black, enemy = piece > 0 ? black : white;
+        const int r = sq1 >> 3, c = sq1 & 7;
+        const int kind = piece < 0 ? -piece : piece;
+        uint64_t m = 0;
+        if (kind == 1 || kind == 3) {
+            const int8_t kdr[8] = {-1, -1, -1, 0, 0, 1, 1, 1}, kdc[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+            const int8_t ndr[8] = {-2, -2, -1, -1, 1, 1, 2, 2}, ndc[8] = {-1, 1, -2, 2, -2, 2, -1, 1};
+            for (int k = 0; k < 8; k++) {
+                int nr = r + (kind == 1 ? kdr[k] : ndr[k]), nc = c + (kind == 1 ? kdc[k] : ndc[k]);
+                if (nr >= 0 && nr < 8 && nc >= 0 && nc < 8) m |= 1ull << (nr * 8 + nc);
+            }
+            return m & ~own;
+        }
+        if (kind == 2) {
+            const int dir = piece > 0 ? 1 : -1;          // white pawns walk up the rows, black pawns down
+            const int start = piece > 0 ? 1 : 6, last = piece > 0 ? 6 : 1; // `last`: the next row would be a promotion -> no move
+            if (r == last) return 0;
+            const int nr = r + dir;
+            if (nr < 0 || nr > 7) return 0;
+            if (r == start) {
+                const uint64_t one = 1ull << (nr * 8 + c), two = 1ull << ((nr + dir) * 8 + c);
+                if (!(occ & one)) {
+                    m |= one;
+                    if (!(occ & two)) m |= two;
+                }
+            } else if (r > 1 && r < 6) {
+                const uint64_t one = 1ull << (nr * 8 + c);
+                if (!(occ & one)) m |= one;
+            }
+            if (c > 0) m |= (1ull << (nr * 8 + c - 1)) & enemy;
+            if (c < 7) m |= (1ull << (nr * 8 + c + 1)) & enemy;
+            return m;
+        }
+        const bool diag = kind == 4 || kind == 6, ortho = kind == 5 || kind == 6;
+        const int8_t sdr[8] = {-1, -1, 1, 1, -1, 1, 0, 0}, sdc[8] = {-1, 1, -1, 1, 0, 0, -1, 1};
+        for (int k = 0; k < 8; k++) {
+            if (k < 4 ? !diag : !ortho) continue;
+            int nr = r + sdr[k], nc = c + sdc[k];
+            while (nr >= 0 && nr < 8 && nc >= 0 && nc < 8) {
+                const uint64_t bit = 1ull << (nr * 8 + nc);
+                if (occ & bit) {
+                    m |= bit & enemy;
+                    break;
+                }
+                m |= bit;
+                nr += sdr[k];
+                nc += sdc[k];
+            }
+        }
+        return m;
+    }
+
     BB_HD static int action_id(int sq1, int sq2) { return sq1 * 63 + sq2 - (sq2 > sq1); } // DragonChess.py:26-34
     BB_HD static void action_squares(int a, int &sq1, int &sq2) {
         sq1 = a / 63;

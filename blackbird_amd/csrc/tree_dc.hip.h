@@ -105,43 +105,80 @@ __device__ __forceinline__ double dc_np_sum(const double *a, int lane) {
 
 // AddChildren for the node `node` (state st): move generation (lane = from-square), priors, edge rows.
 // policy == nullptr -> MCTS.GetPriors default (ones).  lds: 4032 doubles of scratch owned by this wave.
+// board_mem: the 64 board bytes of `st` in memory (one coalesced load instead of dynamic indexing into registers)
 __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *node, const DCState &st,
-                          const float *policy, uint32_t gid, int lane, double *lds) {
-    uint64_t m = DragonChess::targets(st, lane);
+                          const int8_t *board_mem, const float *policy, uint32_t gid, int lane, double *lds) {
+#ifdef BB_STAMPS
+    long long x0 = clock64();
+#endif
+    // move generation: lane = from-square; occupancy by two ballots, targets by bit operations (games.hip.h)
+    const int piece = board_mem[lane];
+    const uint64_t white = __ballot(piece > 0), black = __ballot(piece < 0);
+    uint64_t m = DragonChess::targets_bits(piece, st.player, lane, white, black);
     int cnt = bb_popc64(m);
     int pre = wave_excl_scan_i(cnt, lane);
     int total = wave_sum_i(cnt);
     int off = E.used[g];
     if (off + total > E.edge_cap) return false;
-    double tot = 1.0;
-    if (policy) {
-        for (int i = lane; i < 4032; i += 64) lds[i] = 0.0;
+#ifdef BB_STAMPS
+    long long e0 = clock64(), e1 = e0, e2 = e0;
+    if (lane == 0 && d.stamps && policy) atomicAdd(&d.stamps[9], (unsigned long long)(e0 - x0));
+#endif
+    // The moves are dealt evenly over the lanes (move j of the from-square-major enumeration -> lane j & 63): one
+    // policy load, one Beta draw and one edge per lane instead of a serial loop over the busiest square's moves.
+    constexpr int MPL = 4; // moves per lane: up to 256 legal moves
+    if (total > 64 * MPL) return false;
+    uint16_t *mlist = (uint16_t *)lds; // compact action list, parked in the scratch until every lane has its entries
+    {
         uint64_t mm = m;
+        int k = pre;
         while (mm) {
             int sq2 = bb_ctz64(mm);
             mm &= mm - 1;
-            int a = DragonChess::action_id(lane, sq2);
-            float p = policy[a];
-            if (E.noise_on) p = (1.0f - E.eps) * p + E.eps * bb_beta_noise(d.seed, gid, (uint32_t)node->serial, (uint32_t)a, E.alpha);
-            lds[a] = (double)p; // float32 * float64 legal mask (1.0)
+            mlist[k++] = (uint16_t)DragonChess::action_id(lane, sq2);
         }
+    }
+    __threadfence_block();
+    int mya[MPL];
+#pragma unroll
+    for (int i = 0; i < MPL; i++) mya[i] = (lane + 64 * i < total) ? (int)mlist[lane + 64 * i] : -1;
+    __threadfence_block();
+    double tot = 1.0;
+    float myp[MPL];
+    if (policy) {
+        for (int i = lane; i < 4032; i += 64) lds[i] = 0.0;
+        __threadfence_block();
+#pragma unroll
+        for (int i = 0; i < MPL; i++) {
+            myp[i] = 0.f;
+            if (mya[i] >= 0) {
+                float p = policy[mya[i]];
+                if (E.noise_on)
+                    p = (1.0f - E.eps) * p + E.eps * bb_beta_noise(d.seed, gid, (uint32_t)node->serial, (uint32_t)mya[i], E.alpha);
+                myp[i] = p;
+                lds[mya[i]] = (double)p; // float32 * float64 legal mask (1.0)
+            }
+        }
+#ifdef BB_STAMPS
+        e1 = clock64();
+#endif
         tot = dc_np_sum(lds, lane);
+#ifdef BB_STAMPS
+        e2 = clock64();
+#endif
     }
     size_t base = (size_t)g * E.edge_cap + off;
-    uint64_t mm = m;
-    int k = pre;
-    while (mm) {
-        int sq2 = bb_ctz64(mm);
-        mm &= mm - 1;
-        int a = DragonChess::action_id(lane, sq2);
-        size_t e = base + k++;
-        E.act[e] = (uint16_t)a;
-        E.N[e] = 0;
-        E.Q[e] = 0.f;
-        E.W[e] = 0.f;
-        E.child[e] = CHILD_NONE;
-        E.cP[e] = policy ? d.c_puct * __ddiv_rn(lds[a], tot) : d.c_puct * 1.0;
-    }
+#pragma unroll
+    for (int i = 0; i < MPL; i++)
+        if (mya[i] >= 0) {
+            size_t e = base + lane + 64 * i;
+            E.act[e] = (uint16_t)mya[i];
+            E.N[e] = 0;
+            E.Q[e] = 0.f;
+            E.W[e] = 0.f;
+            E.child[e] = CHILD_NONE;
+            E.cP[e] = policy ? d.c_puct * __ddiv_rn((double)myp[i], tot) : d.c_puct * 1.0;
+        }
     if (lane == 0) {
         node->flags |= NODE_EXPANDED;
         node->n_edges = total;
@@ -150,6 +187,14 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
         node->sq = 1.0;
         E.used[g] = off + total;
     }
+#ifdef BB_STAMPS
+    if (lane == 0 && d.stamps && policy) {
+        atomicAdd(&d.stamps[5], (unsigned long long)(e1 - e0));
+        atomicAdd(&d.stamps[6], (unsigned long long)(e2 - e1));
+        atomicAdd(&d.stamps[7], (unsigned long long)(clock64() - e2));
+        atomicAdd(&d.stamps[8], 1ull);
+    }
+#endif
     return true;
 }
 
@@ -162,7 +207,7 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
     float v = d.eval_value[g];
     if (d.pend_expand[g]) {
         uint32_t gid = d.first_game_id + (uint32_t)d.game_lid[g];
-        if (!dc_expand(d, E, g, node, st, d.eval_policy + (size_t)g * 4032, gid, lane, lds) && lane == 0)
+        if (!dc_expand(d, E, g, node, st, ((const DCState *)d.leaf_state)[g].b, d.eval_policy + (size_t)g * 4032, gid, lane, lds) && lane == 0)
             d.ctr[(size_t)g * 8 + 6] += 1;
     }
     int player = st.player, prev = st.prev;
@@ -174,6 +219,9 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
         if (player != prev) v01 = 1.0f - v01;
     }
     float vflip = 1.0f - v01;
+#ifdef BB_STAMPS
+    long long b0 = clock64();
+#endif
     int plen = d.path_len[g];
     const uint32_t *pn = d.path + (size_t)g * DragonChess::MAXPATH;
     const uint32_t *pe = E.path_edge + (size_t)g * DragonChess::MAXPATH;
@@ -196,6 +244,9 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
         if (pp) d.root_W[g] += (pp == prev) ? v01 : vflip;
         d.pend_leaf[g] = -1;
     }
+#ifdef BB_STAMPS
+    if (lane == 0 && d.stamps) atomicAdd(&d.stamps[10], (unsigned long long)(clock64() - b0));
+#endif
 }
 
 // create the child reached by edge e (absolute) of parent; lane 0 writes
@@ -254,7 +305,7 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
             if (!have_st) st = node->st;
             if (flags & NODE_TERMINAL) { term_leaf = 1; break; }
             if (!inline_expand) { expand = 1; break; }
-            if (!dc_expand(d, E, g, node, st, nullptr, 0u, lane, lds)) { overflow = 1; break; }
+            if (!dc_expand(d, E, g, node, st, node->st.b, nullptr, 0u, lane, lds)) { overflow = 1; break; }
             __threadfence_block();
             if (!fixed) break;
             n_edges = node->n_edges;
@@ -324,9 +375,23 @@ __global__ void __launch_bounds__(256) k_dc_tree_step(TreeDev d, DCEdges E) {
     __shared__ double lds[4][DC_LDS_DOUBLES];
     int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (g >= d.n_slots) return;
+#ifdef BB_STAMPS
+    long long t0 = clock64();
+#endif
     dc_phase_apply(d, E, g, lane, lds[wv]);
+#ifdef BB_STAMPS
+    long long t1 = clock64();
+#endif
     __threadfence_block();
     dc_phase_select(d, E, g, lane, lds[wv]);
+#ifdef BB_STAMPS
+    long long t2 = clock64();
+    if (lane == 0 && d.stamps) {
+        atomicAdd(&d.stamps[0], (unsigned long long)(t1 - t0));
+        atomicAdd(&d.stamps[2], (unsigned long long)(t2 - t1));
+        atomicAdd(&d.stamps[4], 1ull);
+    }
+#endif
 }
 
 __global__ void __launch_bounds__(256) k_dc_tree_apply(TreeDev d, DCEdges E) {
