@@ -52,19 +52,40 @@ __device__ __forceinline__ int wave_excl_scan_i(int v, int lane) {
     }
     return x - v;
 }
-// first maximum (lowest idx on ties); idx < 0 marks "no candidate"
+// first maximum (lowest idx on ties); idx < 0 marks "no candidate".  Two stages instead of a six-step butterfly over
+// (value, index, two payloads) -- 30 cross-lane reads: the wave maximum of the score (DPP inside the rows of 16, two
+// ds_bpermute steps across rows), the smallest index among the lanes that hold it, then two v_readlane for the payloads.
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = __builtin_fmax(v, dpp_step_d<0>(v));
+    v = __builtin_fmax(v, dpp_step_d<1>(v));
+    v = __builtin_fmax(v, dpp_step_d<2>(v));
+    v = __builtin_fmax(v, dpp_step_d<3>(v));
+    v = __builtin_fmax(v, __shfl_xor(v, 16, 64));
+    v = __builtin_fmax(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, dpp_step_i<0>(v));
+    v = min(v, dpp_step_i<1>(v));
+    v = min(v, dpp_step_i<2>(v));
+    v = min(v, dpp_step_i<3>(v));
+    v = min(v, __shfl_xor(v, 16, 64));
+    v = min(v, __shfl_xor(v, 32, 64));
+    return v;
+}
 __device__ __forceinline__ void wave_argmax(double &u, int &idx, int &p0, int &p1) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        double ou = __shfl_xor(u, o, 64);
-        int oi = __shfl_xor(idx, o, 64), q0 = __shfl_xor(p0, o, 64), q1 = __shfl_xor(p1, o, 64);
-        bool take = oi >= 0 && (idx < 0 || ou > u || (ou == u && oi < idx));
-        if (take) {
-            u = ou;
-            idx = oi;
-            p0 = q0;
-            p1 = q1;
-        }
+    const double m = wave_max_f64(idx >= 0 ? u : -2.0); // PUCT scores are >= -1
+    const bool tie = idx >= 0 && u == m;
+    const int kmin = wave_min_i32(tie ? idx : 0x7fffffff);
+    const unsigned long long who = __ballot(tie && idx == kmin);
+    if (who) { // uniform
+        const int w = __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1);
+        p0 = __builtin_amdgcn_readlane(p0, w);
+        p1 = __builtin_amdgcn_readlane(p1, w);
+        u = m;
+        idx = kmin;
+    } else {
+        idx = -1;
     }
 }
 
