@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from blackbird_amd import _lib, weights as W
 game = _lib.GAME_DRAGONCHESS
 t = time.time()
-eng = _lib.Engine(game, n_slots=1024, sims_per_move=400, evaluator=_lib.EVAL_NET, noise_on=True, max_games=2048, max_plies=512)
+eng = _lib.Engine(game, n_slots=1024, sims_per_move=400, evaluator=_lib.EVAL_NET, noise_on=True, max_games=2048, max_plies=int(os.environ.get("DC_MAX_PLIES","512")))
 eng.load_weights(W.flatten(W.init_weights(17, 16, 4, 16, 4032, seed=0)))
 print("create %.1fs" % (time.time() - t))
 eng.selfplay_begin(2048, 1.0)

@@ -3,6 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from blackbird_amd import _lib, weights as W
+if os.environ.get("BB_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["BB_LIB"])
 if os.environ.get('BB_LIB'):
     _lib.LIB_PATH = os.environ['BB_LIB']
 
