@@ -80,9 +80,44 @@ def GenerateTrainingSamples(model, nGames, temp):
     if eng.counters()['overflow']:
         raise _lib.BlackbirdHipError('search tree outgrew the node pool')
     rec, offs, _win = eng.fetch_examples(0, nGames)
-    for g in range(nGames):
-        examples = _records_to_examples(game_cls, rec[offs[g]:offs[g + 1]])
-        model.Conn.PutGames(model.Name, model.Version, game_cls.GameType, [e.SerializeState() for e in examples])
+    # (s, pi, z) of every example in bulk: AsInputArray planes by one bb_game_encode call per chunk, pi = visits / total in
+    # float64 exactly as Node.ChildProbability forms it, wire blobs assembled as one byte matrix -- then one PutGames per
+    # game, as the reference issues them (Blackbird.py:267), inside a single sqlite transaction
+    gi = _lib.game_info(game_cls.GAME_ID)
+
+    def blobs_of(r):
+        st = np.ascontiguousarray(r['state']).view(_lib.STATE_DTYPE[game_cls.GAME_ID]).reshape(len(r), -1)
+        planes = _lib.game_encode(game_cls.GAME_ID, st)
+        tot = r['total'].astype(np.float64)
+        if gi.dense:
+            visits = r['visits'][:, :gi.A].astype(np.float64)
+        else:  # compact child lists (action id, plays): scatter to the dense A-wide vector the reference stores
+            visits = np.zeros((len(r), gi.A), dtype=np.float64)
+            live = np.arange(gi.S)[None, :] < r['n_children'][:, None]
+            rows = np.nonzero(live)[0]
+            visits[rows, r['action'][live]] = r['visits'][live]
+        pi = np.where(tot[:, None] > 0, visits / np.maximum(tot, 1.0)[:, None], 0.0)
+        return proto_wire.encode_states_batch(r['z'].astype(np.float32), pi, planes[:, None])
+
+    per = max(1, (1 << 22) // gi.A)  # chunks of whole games, about 32 MB of pi at a time (DragonChess: 4032 float64 per example)
+    deferred = getattr(model.Conn, 'Deferred', None)
+    ctx = deferred() if deferred is not None else None
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        g = 0
+        while g < nGames:
+            h = g + 1
+            while h < nGames and offs[h + 1] - offs[g] <= per:
+                h += 1
+            blobs = blobs_of(rec[offs[g]:offs[h]])
+            for k in range(g, h):
+                model.Conn.PutGames(model.Name, model.Version, game_cls.GameType,
+                                    blobs[offs[k] - offs[g]:offs[k + 1] - offs[g]])
+            g = h
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
 
 
 def TrainWithExamples(model, batchSize, learningRate, epochs=1, teacher=None, model_override=None,

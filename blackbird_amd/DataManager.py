@@ -24,6 +24,7 @@ class Connection(object):
     def __init__(self, isLocal=True, directory='data'):
         os.makedirs(directory, exist_ok=True)
         self._conn = sqlite3.connect(os.path.join(directory, 'blackbird.db'))
+        self._deferred = False
         self.Cursor = self._conn.cursor()
         have = self.Cursor.execute(
             "SELECT name FROM sqlite_master WHERE type='table' AND name='TrainingStatisticsFact';").fetchone()
@@ -58,7 +59,23 @@ class Connection(object):
         key = self._model_key(name, version)
         self.Cursor.executemany("INSERT INTO GameStateFact(ModelKey, GameType, State) VALUES(?, ?, ?);",
                                 [(key, gameType, g) for g in games])
-        self._conn.commit()
+        if not self._deferred:
+            self._conn.commit()
+
+    def Deferred(self):
+        """Context manager: the PutGames calls inside share one transaction (one commit at exit instead of one per game).
+        GenerateTrainingSamples emits thousands of PutGames back to back once the GPU has finished the games."""
+        conn = self
+
+        class _Ctx(object):
+            def __enter__(self):
+                conn._deferred = True
+
+            def __exit__(self, *exc):
+                conn._deferred = False
+                conn._conn.commit()
+                return False
+        return _Ctx()
 
     def PutTrainingStatistic(self, result, name, version, opName, opVersion=0):
         self.Cursor.execute("INSERT INTO TrainingStatisticsFact(ModelKey, OpponentKey, Result) VALUES(?, ?, ?);",

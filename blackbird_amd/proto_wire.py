@@ -44,6 +44,40 @@ def encode_state(mctsEval, mctsPolicy, boardEncoding, boardDims, policyDims):
     return bytes(out)
 
 
+def encode_states_batch(mctsEval, mctsPolicy, boards):
+    """encode_state for K examples at once: mctsEval float32[K], mctsPolicy float64[K, ...], boards int8[K, 1, H, W, C]
+    (each example's board is the [1, H, W, C] array AsInputArray returns).  Returns a list of K bytes objects, byte for
+    byte what encode_state gives example by example (the dims fields are the int8-cast shapes, Blackbird.py:76-79)."""
+    import numpy as np
+    ev = np.ascontiguousarray(mctsEval, dtype='<f4')
+    K = ev.shape[0]
+    pol = np.ascontiguousarray(mctsPolicy, dtype='<f8').reshape(K, -1)
+    brd = np.ascontiguousarray(boards, dtype=np.int8).reshape(K, -1)
+    bdims = np.array(boards.shape[1:], dtype=np.int64).astype(np.int8).tobytes()
+    pdims = np.array(mctsPolicy.shape[1:], dtype=np.int64).astype(np.int8).tobytes()
+    pb, bb = pol.shape[1] * 8, brd.shape[1]
+    head_p = b'\x12' + _varint(pb) if pb else b''
+    head_b = b'\x1a' + _varint(bb) if bb else b''
+    tail = (b'\x22' + _varint(len(bdims)) + bdims if bdims else b'') + (b'\x2a' + _varint(len(pdims)) + pdims if pdims else b'')
+    L = 5 + len(head_p) + pb + len(head_b) + bb + len(tail)
+    m = np.empty((K, L), dtype=np.uint8)
+    m[:, 0] = 0x0d
+    m[:, 1:5] = ev.view(np.uint8).reshape(K, 4)
+    o = 5
+    m[:, o:o + len(head_p)] = np.frombuffer(head_p, dtype=np.uint8)
+    o += len(head_p)
+    m[:, o:o + pb] = pol.view(np.uint8).reshape(K, pb)
+    o += pb
+    m[:, o:o + len(head_b)] = np.frombuffer(head_b, dtype=np.uint8)
+    o += len(head_b)
+    m[:, o:o + bb] = brd.view(np.uint8)
+    o += bb
+    m[:, o:] = np.frombuffer(tail, dtype=np.uint8)
+    zero = ev.view('<u4') == 0  # proto3 omits a default-valued float (+0.0 only; -0.0 is kept)
+    flat = m.tobytes()
+    return [flat[i * L + (5 if zero[i] else 0):(i + 1) * L] for i in range(K)]
+
+
 def decode_state(blob):
     fields = {1: 0.0, 2: b'', 3: b'', 4: b'', 5: b''}
     pos = 0

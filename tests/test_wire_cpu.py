@@ -78,3 +78,22 @@ def test_training_loss_matches_reference_formulas():
     after = tr.export()
     assert any(not np.array_equal(before[k], after[k]) for k in before if "moving" not in k)
     assert all(np.array_equal(before[k], after[k]) for k in before if "moving" in k)
+
+
+def test_batch_encoder_equals_per_example_encoder():
+    """proto_wire.encode_states_batch (used by GenerateTrainingSamples for all examples at once) is byte for byte the
+    per-example encoder, including the omitted +0.0 eval, the kept -0.0, and the int8-wrapped 4032 policy dim."""
+    from blackbird_amd import proto_wire
+    rng = np.random.RandomState(0)
+    for A, shape in ((7, (6, 7, 3)), (9, (3, 3, 3)), (4032, (8, 8, 17))):
+        K = 40
+        z = rng.choice([-1.0, 0.0, 1.0, -0.0], K).astype(np.float32)
+        pi = rng.rand(K, A)
+        pi[::5] = 0
+        boards = rng.randint(-1, 2, (K, 1) + shape).astype(np.int8)
+        blobs = proto_wire.encode_states_batch(z, pi, boards)
+        for i in range(K):
+            pdims = np.array(pi[i].shape, dtype=np.int64).astype(np.int8)
+            ref = proto_wire.encode_state(z[i], pi[i].tobytes(), boards[i].tobytes(),
+                                          np.array(boards[i].shape, dtype=np.int8).tobytes(), pdims.tobytes())
+            assert ref == blobs[i]
