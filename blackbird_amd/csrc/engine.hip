@@ -657,10 +657,20 @@ static int launch_net(bb_engine *e, int n, const typename G::State *states, cons
                       float *policy, int pstride, hipStream_t st) {
     if (e->general_net)
         return launch_gnet<G>(e, n, nullptr, nullptr, states, planes, game_id, serial, noise, value, logits, policy, pstride, st);
+    // positions per wave: the fewest that still put a wave on every SIMD (1024 waves) -- a single FindMove position
+    // must not pay for the 11 MFMA tiles of a 4-position wave
     constexpr int PW = NetPW<G>::v;
-    int blocks = (n + 4 * PW - 1) / (4 * PW);
-    k_net_fused16<G, PW><<<blocks, 256, 0, st>>>(e->net, n, states, planes, game_id, serial, noise, value, logits,
-                                                  policy, pstride);
+    if (PW > 1 && n <= 1024) {
+        k_net_fused16<G, 1><<<(n + 3) / 4, 256, 0, st>>>(e->net, n, states, planes, game_id, serial, noise, value, logits, policy,
+                                                         pstride);
+    } else if (PW > 2 && n <= 2048) {
+        k_net_fused16<G, 2><<<(n + 7) / 8, 256, 0, st>>>(e->net, n, states, planes, game_id, serial, noise, value, logits, policy,
+                                                         pstride);
+    } else {
+        int blocks = (n + 4 * PW - 1) / (4 * PW);
+        k_net_fused16<G, PW><<<blocks, 256, 0, st>>>(e->net, n, states, planes, game_id, serial, noise, value, logits,
+                                                      policy, pstride);
+    }
     HIPCHK(hipGetLastError());
     return BB_OK;
 }
