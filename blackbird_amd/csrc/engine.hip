@@ -540,6 +540,15 @@ static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slo
     if (rc) return rc;
     const GNetDev &g = e->gnet;
     k_gnet_input<G><<<nblk((size_t)n_max * GG::HW), 256, 0, st>>>(g, n_max, n_ptr, slot_list, states, planes);
+    if ((long)n_max * g.NCB <= 2048 && !n_ptr) {
+        // small batch: one position x one filter block per wave (latency of a lone evaluation: 40 layers x ~25 us
+        // instead of x ~170 us at 256 filters)
+        const int ppw = g.NCB >= 4 ? 4 : (g.NCB >= 2 ? 2 : 1);
+        dim3 grid((n_max + 4 / ppw - 1) / (4 / ppw), (g.NCB + ppw - 1) / ppw);
+        k_gnet_conv<G, true, 1, 1><<<grid, 256, 0, st>>>(g, 0, n_max, n_ptr, nullptr, g.act[0], 0, ppw);
+        for (int l = 0; l < 2 * g.R; l++)
+            k_gnet_conv<G, false, 1, 1><<<grid, 256, 0, st>>>(g, 1 + l, n_max, n_ptr, g.act[l & 1], g.act[(l & 1) ^ 1], l & 1, ppw);
+    } else {
     const int pairs = (g.NCB + GN_FBW - 1) / GN_FBW;
     const int ppw = pairs >= 4 ? 4 : (pairs >= 2 ? 2 : 1); // filter-block pairs per workgroup
     const int groups = (n_max + GG::PPB - 1) / GG::PPB;    // groups of PPB positions
@@ -551,6 +560,7 @@ static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slo
             k_gnet_conv_lds<G><<<grid, 256, 0, st>>>(g, 1 + l, n_max, n_ptr, g.act[l & 1], g.act[(l & 1) ^ 1], l & 1);
         else
             k_gnet_conv<G, false><<<grid, 256, 0, st>>>(g, 1 + l, n_max, n_ptr, g.act[l & 1], g.act[(l & 1) ^ 1], l & 1, ppw);
+    }
     }
     k_gnet_heads<G><<<(n_max + 3) / 4, 256, 0, st>>>(g, e->net, n_max, n_ptr, slot_list, g.act[0], game_id, serial, noise, value,
                                                      logits, policy, pstride);

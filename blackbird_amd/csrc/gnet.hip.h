@@ -70,12 +70,15 @@ __global__ void __launch_bounds__(256) k_gnet_input(GNetDev gd, int n_max, const
 // half the L1 traffic of one filter block per wave.  A workgroup = 4 waves = 8 consecutive filter blocks of the
 // same positions (their B loads hit L1).
 #define GN_FBW 2
-template <class G, bool FIRST>
+// PPB / FBW are template parameters so that a SMALL batch (a single FindMove position, an arena of a few games) can be cut
+// finely -- one position and one filter block per wave: 16x more waves, each with 1/7 of the MFMAs -- instead of
+// leaving 250 CUs idle behind two fat workgroups.
+template <class G, bool FIRST, int PPB = GNetGeom<G>::PPB, int FBW = GN_FBW>
 __global__ void __launch_bounds__(256) k_gnet_conv(GNetDev gd, int layer, int n_max, const int *n_ptr, const float *in,
                                                    float *out, int skip, int pairs_per_wg) {
     using GG = GNetGeom<G>;
-    constexpr int HW = GG::HW, W = GG::W, SLOTS = GG::SLOTS, CP = GG::CP, NT = GG::NT, PPB = GG::PPB, PLANE = GG::PLANE,
-                  CIN = GG::CIN, STEPS0 = GG::STEPS0, FBW = GN_FBW;
+    constexpr int HW = GG::HW, W = GG::W, SLOTS = GG::SLOTS, CP = GG::CP, NT = (PPB * HW + 15) / 16, PLANE = GG::PLANE,
+                  CIN = GG::CIN, STEPS0 = GG::STEPS0;
     const int n = n_ptr ? *n_ptr : n_max;
     // the 4 waves of a workgroup = pairs_per_wg (1, 2 or 4) filter-block pairs x 4/pairs_per_wg groups of PPB positions,
     // so that narrow networks (F < 128) still use every wave

@@ -91,3 +91,27 @@ def test_selfplay_with_general_network_matches_oracle_tree(orc):
     network values (taken from the GPU so that only the search is compared)."""
     from .test_gpu_net import _selfplay_vs_oracle_tree
     _selfplay_vs_oracle_tree(orc, filters=32, blocks=2)
+
+
+@pytest.mark.parametrize("F,R,n", [(32, 2, 1500), (128, 2, 300)])
+def test_large_batch_kernels_equal_small_batch_kernels(orc, F, R, n):
+    """Big batches run the throughput kernels (4 positions x 2 filter blocks per wave; LDS-staged activations from 128
+    filters up), small batches the fine-grained latency launch (1 position x 1 filter block per wave): the same K order,
+    so the same bits -- and both within 1e-5 of the oracle."""
+    game = _lib.GAME_CONNECT4
+    gi = _lib.game_info(game)
+    flat = W.flatten(W.init_weights(gi.C, F, R, 16, gi.A, seed=9, perturb=True))
+    eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)
+    eng.load_weights(flat)
+    rng = np.random.RandomState(F)
+    b, pl = boards_for(game, rng, n)
+    st = _lib.pack_grid(game, b, pl)
+    v, l, p = eng.net_eval(states=st)                      # n * F/16 > 2048: throughput kernels
+    for lo in range(0, n, 50):                             # <= 50 positions a call: latency launch
+        v2, l2, p2 = eng.net_eval(states=st[lo:lo + 50])
+        assert np.array_equal(v2, v[lo:lo + 50]) and np.array_equal(l2, l[lo:lo + 50]) and np.array_equal(p2, p[lo:lo + 50])
+    k = 12
+    ov, ol, op = orc.net_forward(orc.NetWeights(gi.H, gi.W, gi.C, F, R, 16, gi.A, flat), _lib.game_encode(game, st[:k]))
+    assert np.max(np.abs(v[:k] - ov)) <= TOL and np.max(np.abs(p[:k] - op)) <= TOL
+    assert np.max(np.abs(l[:k] - ol) / np.maximum(1.0, np.abs(ol))) <= TOL
+    eng.close()
