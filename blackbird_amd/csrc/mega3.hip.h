@@ -15,6 +15,14 @@
 #pragma once
 #include "mega2.hip.h"
 
+#ifndef T_TREE_PRIO
+#define T_TREE_PRIO 3 // issue priorities of the two kinds of waves (tuning)
+#endif
+#ifndef T_NET_PRIO
+#define T_NET_PRIO 3
+#endif
+#define T_PWT 3 // positions a team takes per pass (8 tiles = 2 per wave)
+
 struct TeamCtl {
     int flag[4]; // flag[tw] = number of synchronisation points wave tw has passed
     int slot[4]; // engine slots of the positions being evaluated
@@ -345,7 +353,7 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
 
 template <class G, int NTEAMS>
 __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev dg, NetDev nd, int visits, int noise_on, int limit_s) {
-    constexpr int S = G::S, GW = 16, T = 4, NETW = NTEAMS * T, TREEW = 12 - NETW, GPT = (GW + TREEW - 1) / TREEW, PWT = 3;
+    constexpr int S = G::S, GW = 16, T = 4, NETW = NTEAMS * T, TREEW = 12 - NETW, GPT = (GW + TREEW - 1) / TREEW, PWT = T_PWT;
     static_assert(GPT * S <= 64, "a tree wave holds at most 64 / S games");
     using NG = NetGeom<G, PWT>;
     constexpr int RMAX = MEGA_RMAX, STEPS0 = NG::STEPS0;
@@ -393,7 +401,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev dg, Net
 
     if (wave >= NETW) { // ---------------- tree waves ----------------
         const int tw = wave - NETW;
-        __builtin_amdgcn_s_setprio(3); // the tree waves are the latency chain of every game
+        __builtin_amdgcn_s_setprio(T_TREE_PRIO);
         const int li = (l64 / S) * TREEW + tw, lane = l64 % S; // games are dealt round-robin to the tree waves
         const bool mine = l64 < GPT * S && li < GW && g0 + li < d.n_slots;
         const int g = g0 + li;
@@ -423,6 +431,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev dg, Net
         }
         if (l64 == 0) atomicAdd(&qc.tree_done, 1);
     } else { // ---------------- network teams ----------------
+        __builtin_amdgcn_s_setprio(T_NET_PRIO);
         const int team = wave / T, tw = wave % T;
         TeamCtl *tc = &tcs[team];
         float *tl = lds + team * NG::WAVE_FLOATS;
