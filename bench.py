@@ -182,7 +182,7 @@ def main():
         else:
             kernel = "k_net_compact<Connect4,4>" if mode == 1 else "k_net_fused16<Connect4,4>"
             if filters != 16:
-                kernel = "k_gnet_conv_lds<Connect4> x %d conv layers + first conv + heads per evaluation batch" % (2 * blocks)
+                kernel = "k_gnet_conv<Connect4,false,4,2> x %d conv layers + first conv + heads per evaluation batch" % (2 * blocks)
             flops_per_launch = flops_per_eval * cnt["evals"] / (K * args.sims)
         achieved = flops_per_launch / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
         out = {

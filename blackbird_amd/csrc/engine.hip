@@ -554,13 +554,8 @@ static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slo
     const int groups = (n_max + GG::PPB - 1) / GG::PPB;    // groups of PPB positions
     dim3 grid((groups + 4 / ppw - 1) / (4 / ppw), (pairs + ppw - 1) / ppw);
     k_gnet_conv<G, true><<<grid, 256, 0, st>>>(g, 0, n_max, n_ptr, nullptr, g.act[0], 0, ppw);
-    const bool staged = g.NCB % (4 * GN_FBW) == 0 && !(getenv("BB_GNET_NOLDS") && atoi(getenv("BB_GNET_NOLDS"))); // wide networks: B operand through LDS
-    for (int l = 0; l < 2 * g.R; l++) {
-        if (staged)
-            k_gnet_conv_lds<G><<<grid, 256, 0, st>>>(g, 1 + l, n_max, n_ptr, g.act[l & 1], g.act[(l & 1) ^ 1], l & 1);
-        else
-            k_gnet_conv<G, false><<<grid, 256, 0, st>>>(g, 1 + l, n_max, n_ptr, g.act[l & 1], g.act[(l & 1) ^ 1], l & 1, ppw);
-    }
+    for (int l = 0; l < 2 * g.R; l++)
+        k_gnet_conv<G, false><<<grid, 256, 0, st>>>(g, 1 + l, n_max, n_ptr, g.act[l & 1], g.act[(l & 1) ^ 1], l & 1, ppw);
     }
     k_gnet_heads<G><<<(n_max + 3) / 4, 256, 0, st>>>(g, e->net, n_max, n_ptr, slot_list, g.act[0], game_id, serial, noise, value,
                                                      logits, policy, pstride);

@@ -10,7 +10,8 @@
 //    are constant offsets, no bounds checks anywhere;
 //  * a wave = 2 filter blocks x NT pixel tiles; a workgroup = 4 waves = 8 consecutive 16-filter blocks of the SAME
 //    PPB positions, so the B operand (activations) of a (tap, cb) step is shared through L1 by the 4 waves; each
-//    wave streams its own pre-swizzled A operands (weights) once per NT pixel tiles;
+//    wave streams its own pre-swizzled A operands (weights) once per NT pixel tiles; operands are prefetched two
+//    steps ahead in three register sets, with scheduling barriers so that the compiler keeps the distance;
 //  * K order per output pixel is (16-channel block, tap, r, j), c = 16 cb + 4 j + r: the 9 shifted views of one
 //    channel block (17 KB for 4 positions) are consumed together, so they are L1/L2 hits instead of 9 passes over
 //    the whole activation tensor -- and it is exactly the CPU restatement's fmaf
@@ -197,124 +198,6 @@ __global__ void __launch_bounds__(256) k_gnet_conv(GNetDev gd, int layer, int n_
             f32x4 y;
             f32x4 sk = {0.f, 0.f, 0.f, 0.f};
             if (skip && valid[t]) sk = *(const f32x4 *)(op + ooff[t] + fo); // tf.add(batch_norm_2, block input) before the ReLU
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = __builtin_fmaf(acc[f][t][r], scale[r], shift[r]);
-                if (skip) v = v + sk[r];
-                y[r] = fmaxf(v, 0.f);
-            }
-            if (valid[t]) *(f32x4 *)(op + ooff[t] + fo) = y;
-        }
-    }
-}
-
-// ---- tower layer for wide networks (>= 8 filter blocks): the B operand staged through LDS ---------------------------
-// With every wave loading its own copy of the activations the 4 waves of a workgroup ask L1 for 52 KB per (cb, tap)
-// step and the vector-memory path, not the MFMA pipe, sets the pace (measured: -10 % time with either operand
-// stream removed).  Here the workgroup loads each step's 11 KB of activations ONCE (a quarter per wave), parks them
-// in a three-stage LDS ring and every wave reads its B operands from there; only the A operand stays private.
-// One workgroup barrier per step.
-template <class G>
-__global__ void __launch_bounds__(256) k_gnet_conv_lds(GNetDev gd, int layer, int n_max, const int *n_ptr, const float *in,
-                                                       float *out, int skip) {
-    using GG = GNetGeom<G>;
-    constexpr int HW = GG::HW, W = GG::W, NT = GG::NT, PPB = GG::PPB, PLANE = GG::PLANE, FBW = GN_FBW;
-    constexpr int TPW = (NT + 3) / 4; // tiles a wave fetches per step
-    __shared__ f32x4 ring[3][NT][64];
-    const int n = n_ptr ? *n_ptr : n_max;
-    const int pos0 = blockIdx.x * PPB;
-    if (pos0 >= n) return; // whole workgroup
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane >> 4, nn = lane & 15;
-    const int NCB = gd.NCB;
-    const int fb0 = (blockIdx.y * 4 + wave) * FBW; // the host launches this kernel only when NCB % (4*FBW) == 0
-    const size_t pos_floats = (size_t)NCB * 4 * PLANE;
-    int ooff[NT];
-    bool valid[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        int q = t * 16 + nn;
-        int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
-        valid[t] = pp < PPB && pos0 + pp < n;
-        if (pp >= PPB) pp = PPB - 1;
-        ooff[t] = (int)(pp * pos_floats) + j * PLANE + ((y + 1) * (W + 1) + (x + 1)) * 4;
-    }
-    int goff[TPW]; // the tiles this wave fetches: wave, wave+4, ...
-#pragma unroll
-    for (int k = 0; k < TPW; k++) {
-        int t = wave + 4 * k;
-        int q = (t < NT ? t : NT - 1) * 16 + nn;
-        int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
-        if (pp >= PPB) pp = PPB - 1;
-        goff[k] = (int)(pp * pos_floats) + j * PLANE + ((y + 1) * (W + 1) + (x + 1)) * 4;
-    }
-    f32x4 acc[FBW][NT];
-#pragma unroll
-    for (int f = 0; f < FBW; f++) {
-        const f32x4 bias = *(const f32x4 *)(gd.epi + ((size_t)layer * NCB + fb0 + f) * 48 + 4 * j);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[f][t] = bias;
-    }
-    const float *ip = in + (size_t)pos0 * pos_floats;
-    const f32x4 *wp[FBW];
-#pragma unroll
-    for (int f = 0; f < FBW; f++) wp[f] = gd.wt + (((size_t)(layer - 1) * NCB + fb0 + f) * 9) * NCB * 64 + lane;
-    const int steps = 9 * NCB, last = steps - 1;
-    auto toff_of = [&](int s) {
-        const int cb = s / 9, tap = s - 9 * cb;
-        return ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * 4 + cb * 4 * PLANE;
-    };
-    auto fetch = [&](f32x4 (&g)[TPW], int s) { // this wave's share of step s's activations
-        const int toff = toff_of(s < last ? s : last);
-#pragma unroll
-        for (int k = 0; k < TPW; k++) g[k] = *(const f32x4 *)(ip + goff[k] + toff);
-    };
-    auto park = [&](const f32x4 (&g)[TPW], int stage) {
-#pragma unroll
-        for (int k = 0; k < TPW; k++)
-            if (wave + 4 * k < NT) ring[stage][wave + 4 * k][lane] = g[k];
-    };
-    f32x4 g0[TPW], g1[TPW], a_cur[FBW], a_nxt[FBW];
-    fetch(g0, 0);
-    fetch(g1, 1);
-#pragma unroll
-    for (int f = 0; f < FBW; f++) a_cur[f] = wp[f][0];
-    park(g0, 0);
-    park(g1, 1);
-    fetch(g0, 2); // in flight during step 0, parked at its end
-    __syncthreads();
-    for (int s = 0; s < steps; s++) {
-        const int sn = s + 1 < last ? s + 1 : last;
-#pragma unroll
-        for (int f = 0; f < FBW; f++) a_nxt[f] = wp[f][(size_t)sn * 64];
-        f32x4 b[NT];
-#pragma unroll
-        for (int t = 0; t < NT; t++) b[t] = ring[s % 3][t][lane];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int t = 0; t < NT; t++)
-#pragma unroll
-                for (int f = 0; f < FBW; f++)
-                    acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[f][r], b[t][r], acc[f][t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        park(g0, (s + 2) % 3); // stage (s+2)%3 == (s-1)%3 was last read in step s-1, before the previous barrier
-        fetch(g0, s + 3);
-#pragma unroll
-        for (int f = 0; f < FBW; f++) a_cur[f] = a_nxt[f];
-        __syncthreads();
-    }
-    float *op = out + (size_t)pos0 * pos_floats;
-#pragma unroll
-    for (int f = 0; f < FBW; f++) {
-        const float *ep = gd.epi + ((size_t)layer * NCB + fb0 + f) * 48;
-        const f32x4 scale = *(const f32x4 *)(ep + 16 + 4 * j), shift = *(const f32x4 *)(ep + 32 + 4 * j);
-        const int fo = (fb0 + f) * 4 * PLANE;
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            f32x4 y;
-            f32x4 sk = {0.f, 0.f, 0.f, 0.f};
-            if (skip && valid[t]) sk = *(const f32x4 *)(op + ooff[t] + fo);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 float v = __builtin_fmaf(acc[f][t][r], scale[r], shift[r]);

@@ -95,8 +95,7 @@ def test_selfplay_with_general_network_matches_oracle_tree(orc):
 
 @pytest.mark.parametrize("F,R,n", [(32, 2, 1500), (128, 2, 300)])
 def test_large_batch_kernels_equal_small_batch_kernels(orc, F, R, n):
-    """Big batches run the throughput kernels (4 positions x 2 filter blocks per wave; LDS-staged activations from 128
-    filters up), small batches the fine-grained latency launch (1 position x 1 filter block per wave): the same K order,
+    """Big batches run the throughput launch (4 positions x 2 filter blocks per wave), small batches the fine-grained latency launch (1 position x 1 filter block per wave): the same K order,
     so the same bits -- and both within 1e-5 of the oracle."""
     game = _lib.GAME_CONNECT4
     gi = _lib.game_info(game)
