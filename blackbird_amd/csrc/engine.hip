@@ -477,6 +477,7 @@ static int gnet_reserve(bb_engine *e, int n) {
     if (dalloc(e, g.inp, (size_t)cap * GG::SLOTS * GG::CP) || dalloc(e, g.act[0], (size_t)cap * pos_floats) ||
         dalloc(e, g.act[1], (size_t)cap * pos_floats))
         return BB_ERR_HIP; // zero-filled: the halo ring of every position stays zero for the buffers' lifetime
+    HIPCHK(sync_all(e)); // the fills ran on the engine stream; the caller may launch on another one
     g.cap = cap;
     return BB_OK;
 }
@@ -534,11 +535,20 @@ static int load_general_weights(bb_engine *e, const bb_net_weights *w) {
 template <class G>
 static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slot_list, const typename G::State *states,
                        const int8_t *planes, const uint32_t *game_id, const int32_t *serial, int noise, float *value,
-                       float *logits, float *policy, int pstride, hipStream_t st) {
+                       float *logits, float *policy, int pstride, hipStream_t st, int buf_offset = 0) {
+    // buf_offset: first position of the activation buffers this call may use (the two slot-range views of pipelined
+    // rounds run on two streams at once and must not share scratch)
     using GG = GNetGeom<G>;
-    int rc = gnet_reserve<G>(e, n_max);
+    buf_offset = (buf_offset + GG::PPB - 1) / GG::PPB * GG::PPB;
+    int rc = gnet_reserve<G>(e, buf_offset + n_max);
     if (rc) return rc;
-    const GNetDev &g = e->gnet;
+    GNetDev g = e->gnet;
+    {
+        const size_t pos_floats = (size_t)g.NCB * 4 * GG::PLANE;
+        g.inp += (size_t)buf_offset * GG::SLOTS * GG::CP;
+        g.act[0] += (size_t)buf_offset * pos_floats;
+        g.act[1] += (size_t)buf_offset * pos_floats;
+    }
     k_gnet_input<G><<<nblk((size_t)n_max * GG::HW), 256, 0, st>>>(g, n_max, n_ptr, slot_list, states, planes);
     if ((long)n_max * g.NCB <= 2048 && !n_ptr) {
         // small batch: one position x one filter block per wave (latency of a lone evaluation: 40 layers x ~25 us
@@ -1055,7 +1065,8 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
                     if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], st));
                     if (e->general_net) {
                         int rc = launch_gnet<G>(e, d.n_slots, d.post_count + (round & 3), d.post_slot, ls, nullptr, d.leaf_game_id,
-                                                d.leaf_serial, e->cfg.noise_on, d.eval_value, nullptr, d.eval_policy, G::S, st);
+                                                d.leaf_serial, e->cfg.noise_on, d.eval_value, nullptr, d.eval_policy, G::S, st,
+                                                d.slot_offset);
                         if (rc) return rc;
                     } else
                     k_net_compact<G, PWMAX><<<nb, 256, 0, st>>>(e->net, d.post_count + (round & 3), d.post_slot, ls,

@@ -114,3 +114,11 @@ def test_large_batch_kernels_equal_small_batch_kernels(orc, F, R, n):
     assert np.max(np.abs(v[:k] - ov)) <= TOL and np.max(np.abs(p[:k] - op)) <= TOL
     assert np.max(np.abs(l[:k] - ol) / np.maximum(1.0, np.abs(ol))) <= TOL
     eng.close()
+
+
+def test_wide_network_rounds_on_two_streams(orc, monkeypatch):
+    """BB_MEGA=0 with >= 512 slots pipelines two slot-range views on two streams; with a wide network both run the
+    general path at once and must not share activation scratch: self-play still equals the oracle's search."""
+    monkeypatch.setenv("BB_MEGA", "0")
+    from .test_gpu_net import _selfplay_vs_oracle_tree
+    _selfplay_vs_oracle_tree(orc, filters=32, blocks=1, n_slots=512, n_games=24, sims=16)
