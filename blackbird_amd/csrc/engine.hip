@@ -188,6 +188,8 @@ struct bb_engine {
     int net_F = 0, net_C = 0;
     bool general_net = false; // F != 16 (or BB_GNET=1): one implicit-GEMM launch per conv layer (gnet.hip.h)
     GNetDev gnet = {};
+    int gnet_C = 0;
+    size_t net_sizes[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
     int n_games_target = 0;
@@ -515,13 +517,20 @@ static int load_general_weights(bb_engine *e, const bb_net_weights *w) {
         }
     }
     GNetDev &g = e->gnet;
-    g = GNetDev{};
-    g.F = F;
-    g.NCB = NCB;
-    g.R = R;
-    float *d_w0, *d_wt, *d_epi;
-    if (dalloc(e, d_w0, w0.size(), false) || dalloc(e, d_wt, wt.size(), false) || dalloc(e, d_epi, epi.size(), false))
-        return BB_ERR_HIP;
+    // weights are reloaded after every training step: keep the device buffers (operands and activation scratch) when
+    // the network shape is unchanged instead of allocating new ones each time
+    const bool same = g.F == F && g.R == R && g.NCB == NCB && g.w0 && e->gnet_C == C;
+    float *d_w0 = (float *)g.w0, *d_wt = (float *)g.wt, *d_epi = (float *)g.epi;
+    if (!same) {
+        g = GNetDev{};
+        g.F = F;
+        g.NCB = NCB;
+        g.R = R;
+        e->gnet_C = C;
+        if (dalloc(e, d_w0, w0.size(), false) || dalloc(e, d_wt, wt.size(), false) || dalloc(e, d_epi, epi.size(), false))
+            return BB_ERR_HIP;
+    }
+    HIPCHK(sync_all(e));
     HIPCHK(hipMemcpy(d_w0, w0.data(), w0.size() * 4, hipMemcpyHostToDevice));
     if (!wt.empty()) HIPCHK(hipMemcpy(d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_epi, epi.data(), epi.size() * 4, hipMemcpyHostToDevice));
@@ -635,10 +644,16 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     nd.off_pdk = push(w->p_d_k, 2 * A);
     nd.off_pdb = push(w->p_d_b, A);
     nd.head_floats = (int)head.size();
-    float *d_w0, *d_wt, *d_epi, *d_head;
-    if (dalloc(e, d_w0, w0.size(), false) || dalloc(e, d_wt, wt.size(), false) || dalloc(e, d_epi, epi.size(), false) ||
-        dalloc(e, d_head, head.size(), false))
-        return BB_ERR_HIP;
+    // (weights are reloaded after every training step: the operand buffers are reused while their sizes stay the same)
+    float *d_w0 = (float *)nd.w0, *d_wt = (float *)nd.wt, *d_epi = (float *)nd.epi, *d_head = (float *)nd.head;
+    const size_t sizes[4] = {w0.size(), wt.size(), epi.size(), head.size()};
+    if (!d_w0 || memcmp(sizes, e->net_sizes, sizeof(sizes)) != 0) {
+        if (dalloc(e, d_w0, w0.size(), false) || dalloc(e, d_wt, wt.size(), false) || dalloc(e, d_epi, epi.size(), false) ||
+            dalloc(e, d_head, head.size(), false))
+            return BB_ERR_HIP;
+        memcpy(e->net_sizes, sizes, sizeof(sizes));
+    }
+    HIPCHK(sync_all(e));
     HIPCHK(hipMemcpy(d_w0, w0.data(), w0.size() * 4, hipMemcpyHostToDevice));
     if (!wt.empty()) HIPCHK(hipMemcpy(d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_epi, epi.data(), epi.size() * 4, hipMemcpyHostToDevice));
