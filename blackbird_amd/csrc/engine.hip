@@ -1038,6 +1038,9 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
             if (e->mega_queue == 2) {
                 int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
                 if constexpr (G::S == 8) {
+                    if (getenv("BB_TEAM_WAVES") && atoi(getenv("BB_TEAM_WAVES")) == 2) // four teams of two waves, two positions per pass
+                        k_selfplay_team<G, 4, 2, 2><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
+                    else
                         k_selfplay_team<G, 2><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
                 } else
                     k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);

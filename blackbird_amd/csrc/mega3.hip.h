@@ -188,7 +188,9 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
                                               const int32_t *serial, int noise, float *value_out, float *policy_out,
                                               int pstride, QueueCtl *qc, long long t_start, long long t_limit TS_ARG) {
     TS_INIT
-    static_assert(T == 4, "head roles and the tile deal are written for teams of four waves");
+    static_assert(T == 4 || T == 2, "head roles are written for teams of four or two waves");
+    // head roles: teams of four = value / policy / noise / (idle); teams of two = value + noise / policy
+    constexpr int ROLE_VALUE = 0, ROLE_POLICY = 1, ROLE_NOISE = T == 4 ? 2 : 0;
     using NG = NetGeom<G, PW>;
     constexpr int W = NG::W, CIN = NG::CIN, A = NG::A, HW = NG::HW, SLOTS = NG::SLOTS, CP = NG::CP, ACT = NG::ACT,
                   PLANE = NG::PLANE;
@@ -216,11 +218,19 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
     TSTAMP(0);
     // ---- tower: tiles tw and tw+4 of the ceil(n*HW/16) tiles that hold real pixels
     const int ntiles = (n * HW + 15) / 16;
-    const int mine = ntiles > tw + T ? 2 : (ntiles > tw ? 1 : 0);
+    constexpr int NTWMAX = (NG::NT + T - 1) / T;
+    const int mine = (NTWMAX >= 3 && ntiles > tw + 2 * T) ? 3 : (ntiles > tw + T ? 2 : (ntiles > tw ? 1 : 0));
     bool ok;
+    if constexpr (NTWMAX >= 3) {
+        if (mine == 3) {
+            ok = net_team_tower<G, PW, T, 3>(nd, n, tl, tc, tw, epoch, qc, t_start, t_limit TS_PASS);
+            goto tower_done;
+        }
+    }
     if (mine == 2) ok = net_team_tower<G, PW, T, 2>(nd, n, tl, tc, tw, epoch, qc, t_start, t_limit TS_PASS);
     else if (mine == 1) ok = net_team_tower<G, PW, T, 1>(nd, n, tl, tc, tw, epoch, qc, t_start, t_limit TS_PASS);
     else ok = net_team_tower<G, PW, T, 0>(nd, n, tl, tc, tw, epoch, qc, t_start, t_limit TS_PASS);
+tower_done:
     if (!ok) return false;
 #ifdef BB_STAMPS
     _ts = clock64();
@@ -233,7 +243,7 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
     float *sd = rp + 2 * PW * HW; // [PW][D]                                (wave 0)
     float *lg = sd + PW * D;      // [PW][A]                                (wave 1)
     float *nz = lg + PW * A;      // [PW][A]    Beta draws                  (wave 2 writes, wave 1 reads)
-    if (tw == 0) {
+    if (tw == ROLE_VALUE) {
         const float *vk = hp + nd.off_vk, *v3 = hp + nd.off_v3;
         for (int q = lane; q < n * HW; q += 64) {
             int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
@@ -263,7 +273,8 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
         }
         for (int i = lane; i < PW * HW; i += 64) rv[i] = 0.f; // the scratch overlays halo slots: restore the zeros
         for (int i = lane; i < PW * D; i += 64) sd[i] = 0.f;
-    } else if (tw == 1) {
+    }
+    if (tw == ROLE_POLICY) {
         const float *pk = hp + nd.off_pk, *p6 = hp + nd.off_p6;
         for (int q = lane; q < n * HW; q += 64) {
             int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
@@ -291,7 +302,8 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
                 s += __builtin_fmaf(rp[2 * (pp * HW + p) + 1], k1, __builtin_fmaf(rp[2 * (pp * HW + p)], k0, kb));
             lg[q] = s;
         }
-    } else if (tw == 2) {
+    }
+    if (tw == ROLE_NOISE) {
         if (noise) { // two lanes per (position, action): lane pair (2i, 2i+1) tries Philox pairs k and k+1 side by side
             const float ia = 1.0f / nd.alpha, ib = 1.0f / (1.0f - nd.alpha);
             for (int base = 0; base < n * A; base += 32) {
@@ -312,10 +324,10 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
         }
     }
     TSTAMP(4);
-    // wave 1 needs wave 2's draws; nobody else waits here
+    // the policy wave needs the noise wave's draws; nobody else waits here
     team_bump(tc, tw, epoch);
-    if (tw == 1) {
-        if (!team_wait(tc, 2, epoch, qc, t_start, t_limit)) return false;
+    if (tw == ROLE_POLICY) {
+        if (!team_wait(tc, ROLE_NOISE, epoch, qc, t_start, t_limit)) return false;
         if (lane < n) { // one lane finishes each position (sequential, oracle order)
             const int pp = lane, pos = slot_list[lane];
             float m = -INFINITY;
@@ -351,9 +363,9 @@ __device__ __forceinline__ bool net_team_body(const NetDev &nd, int n, const int
     return true;
 }
 
-template <class G, int NTEAMS>
+template <class G, int NTEAMS, int T = 4, int PWT = T_PWT>
 __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_team(TreeDev dg, NetDev nd, int visits, int noise_on, int limit_s) {
-    constexpr int S = G::S, GW = 16, T = 4, NETW = NTEAMS * T, TREEW = 12 - NETW, GPT = (GW + TREEW - 1) / TREEW, PWT = T_PWT;
+    constexpr int S = G::S, GW = 16, NETW = NTEAMS * T, TREEW = 12 - NETW, GPT = (GW + TREEW - 1) / TREEW;
     static_assert(GPT * S <= 64, "a tree wave holds at most 64 / S games");
     using NG = NetGeom<G, PWT>;
     constexpr int RMAX = MEGA_RMAX, STEPS0 = NG::STEPS0;
