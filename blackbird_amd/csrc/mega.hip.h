@@ -30,12 +30,6 @@
 #define MEGA_RMAX 4       // residual blocks whose weights fit the 160 KiB LDS next to the activations
 #define MEGA_HEAD_FLOATS 256
 
-// out-of-line so that the tree code gets its own register allocation instead of squeezing the MFMA loop
-template <class G>
-__device__ __attribute__((noinline)) bool async_game_call(const TreeDev &d, int g, int lane) {
-    return async_game<G>(d, g, lane);
-}
-
 template <class G>
 __global__ void __launch_bounds__(MEGA_THREADS) k_selfplay_mega(TreeDev d, NetDev nd, int phases, int noise_on) {
     constexpr int S = G::S, GW = 16, SET = 8, PW = MEGA_PW, NETW = SET / PW; // NETW network waves, then 4 tree waves
