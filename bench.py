@@ -5,9 +5,11 @@ Workload (configs[1], "C2"): Connect4 7x6, 800 simulations/move, 4096 concurrent
 per GPU, network R4/F16/D16 random-init (weight seed 0), c_puct 0.85, temp 1, Beta prior noise
 alpha 0.2 / eps 0.3 (always on in the reference, NetworkFactory.py:176-180), float32.
 
-A "step" is one ply of every concurrent game: 800 x (tree kernel + network kernel) + one move
-kernel.  Finished games hand their slot to a fresh game, so the batch stays full; `value` is
-games completed inside the timed region / wall time (whole job, all ranks).  Before warm-up the
+A "step" is one ply of every concurrent game: 800 visits of every game by the persistent self-play kernel (or
+800 x (tree kernel + network kernel) + one move kernel in the launch-per-round modes).  Finished games hand their
+slot to a fresh game, so the batch stays full; `value` is games completed inside the timed region / wall time (whole
+job, all ranks).  The timed region = the K steps + the extraction to the host of the example records of as many
+finished games as it produced (SURVEY.md 8d counts example extraction in the metric).  Before warm-up the
 games are de-synchronised by an untimed prefill at 32 simulations/move (otherwise all 4096 games
 would start and finish in lock-step and a short timed window would see no completions).
 
@@ -143,10 +145,15 @@ def main():
     t0 = time.perf_counter()
     eng.selfplay_step(K)
     eng.synchronize()
+    # example extraction belongs to the metric ("all kernels + host orchestration + example extraction")
+    # -- as many finished games as the timed region produced (the oldest ids: complete records) come back to the host
+    tf = time.perf_counter()
+    cnt = eng.counters()
+    rec_t, _offs_t, _win_t = eng.fetch_examples(0, max(int(cnt["games_finished"]), 1))
+    fetch_s = time.perf_counter() - tf
     barrier()
     dt = time.perf_counter() - t0
 
-    cnt = eng.counters()
     net_ms, net_min_ms, net_n = eng.timing_read()
     games, sims, plies = cnt["games_finished"], cnt["sims"], cnt["plies"]
     tot = np.array([games, sims, plies, dt], dtype=np.float64)
@@ -198,7 +205,7 @@ def main():
                        "launch_structure": ["lockstep", "async-rounds", "persistent-phases", "persistent-queue", "persistent-teams"][mode],
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
             "node_evals_per_sec": sims / dt, "net_evals_per_sec_rank0": cnt["evals"] / dt, "plies_per_sec": plies / dt,
-            "games_finished": games, "terminal_leaf_fraction": cnt["terminal_leaves"] / max(cnt["sims"], 1),
+            "games_finished": games, "examples_fetched": int(len(rec_t)), "examples_fetch_s": fetch_s, "terminal_leaf_fraction": cnt["terminal_leaves"] / max(cnt["sims"], 1),
             "mean_leaf_depth": cnt["sum_depth"] / max(cnt["sims"], 1), "overflow": cnt["overflow"],
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
