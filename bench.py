@@ -180,7 +180,7 @@ def main():
     if rank == 0:
         mode = eng.selfplay_mode()
         if mode >= 2:
-            # persistent kernel: ONE launch covers the timed region; its FLOPs are the evaluations it performed
+            # persistent kernel: a launch covers up to 16 plies; its FLOPs are the evaluations it performed
             kernel = {2: "k_selfplay_mega<Connect4> (4 network + 4 tree waves per CU, lock-step phases)",
                       3: "k_selfplay_queue<Connect4,8> (8 network + 4 tree waves per CU, LDS work queue)",
                       4: "k_selfplay_team<Connect4,2> (2 teams of 3 network waves + 6 tree waves per CU)"}[mode]
