@@ -151,19 +151,23 @@ static int game_encode(int n, const void *states, int8_t *out) {
 #define GAME_SWITCH_ALL GAME_SWITCH
 
 extern "C" int bb_game_legal(int game, int n, const void *states, uint8_t *legal_out) {
-    if (n <= 0 || !states || !legal_out) return fail(BB_ERR_ARG, "bad arguments");
+    if (n == 0) return BB_OK; // an empty batch is a no-op
+    if (n < 0 || !states || !legal_out) return fail(BB_ERR_ARG, "bad arguments");
     GAME_SWITCH_ALL(game, return game_legal<G>(n, states, legal_out));
 }
 extern "C" int bb_game_apply(int game, int n, void *states, const int32_t *actions, int32_t *status_out) {
-    if (n <= 0 || !states || !actions) return fail(BB_ERR_ARG, "bad arguments");
+    if (n == 0) return BB_OK;
+    if (n < 0 || !states || !actions) return fail(BB_ERR_ARG, "bad arguments");
     GAME_SWITCH_ALL(game, return game_apply<G>(n, states, actions, status_out));
 }
 extern "C" int bb_game_winner(int game, int n, const void *states, const int32_t *prev, int8_t *winner_out) {
-    if (n <= 0 || !states || !winner_out) return fail(BB_ERR_ARG, "bad arguments");
+    if (n == 0) return BB_OK;
+    if (n < 0 || !states || !winner_out) return fail(BB_ERR_ARG, "bad arguments");
     GAME_SWITCH_ALL(game, return game_winner<G>(n, states, prev, winner_out));
 }
 extern "C" int bb_game_encode(int game, int n, const void *states, int8_t *planes_out) {
-    if (n <= 0 || !states || !planes_out) return fail(BB_ERR_ARG, "bad arguments");
+    if (n == 0) return BB_OK;
+    if (n < 0 || !states || !planes_out) return fail(BB_ERR_ARG, "bad arguments");
     GAME_SWITCH_ALL(game, return game_encode<G>(n, states, planes_out));
 }
 extern "C" int bb_game_initial(int game, void *state_out) {
@@ -729,7 +733,8 @@ static int net_eval(bb_engine *e, int n, const void *states, const int8_t *plane
 
 extern "C" int bb_net_eval(bb_engine *e, int n, const void *states, const int8_t *planes, float *value_out,
                            float *logits_out, float *policy_out, int noise) {
-    if (!e || n <= 0 || (!states == !planes)) return fail(BB_ERR_ARG, "bad arguments (exactly one of states/planes)");
+    if (e && n == 0) return BB_OK; // an empty batch is a no-op
+    if (!e || n < 0 || (!states == !planes)) return fail(BB_ERR_ARG, "bad arguments (exactly one of states/planes)");
     if (!e->has_weights) return fail(BB_ERR_WEIGHTS, "bb_load_weights has not been called");
     HIPCHK(hipSetDevice(e->cfg.device));
     GAME_SWITCH(e->cfg.game, return net_eval<G>(e, n, states, planes, value_out, logits_out, policy_out, noise));
@@ -755,7 +760,8 @@ static int hash_eval(bb_engine *e, int n, const void *states, float *value, floa
 }
 
 extern "C" int bb_hash_eval(bb_engine *e, int n, const void *states, float *value_out, float *policy_out) {
-    if (!e || n <= 0 || !states) return fail(BB_ERR_ARG, "bad arguments");
+    if (e && n == 0) return BB_OK;
+    if (!e || n < 0 || !states) return fail(BB_ERR_ARG, "bad arguments");
     HIPCHK(hipSetDevice(e->cfg.device));
     GAME_SWITCH(e->cfg.game, return hash_eval<G>(e, n, states, value_out, policy_out));
 }

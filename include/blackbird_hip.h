@@ -67,7 +67,7 @@ const char *bb_last_error(void);
 int bb_device_count(void);
 
 /* ---- batched game kernels (stateless) ---------------------------------------------------
- * n boards per call, one packed state each.                                               */
+ * n boards per call, one packed state each; n == 0 is a no-op (BB_OK, nothing touched).      */
 /* GameState.LegalActions (Connect4.py:30-36, TicTacToe.py:29-36, DragonChess.py:78-106):
  * legal_out[n][A] bytes 0/1. */
 int bb_game_legal(int game, int n, const void *states, uint8_t *legal_out);

@@ -75,3 +75,17 @@ def test_product_does_not_use_oracle():
             if f.endswith((".py", ".hip", ".h", "Makefile")):
                 src = open(os.path.join(dp, f)).read()
                 assert not pat.search(src), os.path.join(dp, f)
+
+
+def test_empty_batches_are_noops():
+    """n == 0 through the batched entry points: BB_OK and empty outputs, without touching a GPU."""
+    import numpy as np
+    from blackbird_amd import _lib
+    for game in (_lib.GAME_CONNECT4, _lib.GAME_TICTACTOE, _lib.GAME_DRAGONCHESS):
+        gi = _lib.game_info(game)
+        st0 = _lib.game_initial(game)[:0] if _lib.lib().bb_device_count() > 0 else np.zeros((0, gi.state_bytes // np.dtype(_lib.STATE_DTYPE[game]).itemsize), dtype=_lib.STATE_DTYPE[game])
+        assert _lib.game_legal(game, st0).shape == (0, gi.A)
+        assert _lib.game_encode(game, st0).shape == (0, gi.H, gi.W, gi.C)
+        assert _lib.game_winner(game, st0).shape == (0,)
+        ns, status = _lib.game_apply(game, st0, np.zeros(0, np.int32))
+        assert ns.shape[0] == 0 and status.shape == (0,)

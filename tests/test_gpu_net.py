@@ -147,3 +147,24 @@ def _selfplay_vs_oracle_tree(orc, filters, blocks, game=_lib.GAME_CONNECT4, og=0
         assert np.array_equal(r["visits"][:, :gi.A] / tot, o["pi"]), gidx
     eng.close()
     ev.close()
+
+
+def test_empty_and_single_position_batches():
+    """n = 0 is a no-op; n = 1 (the FindMove case) takes the one-position-per-wave launch and equals the same position
+    inside a large batch bit for bit."""
+    game = _lib.GAME_CONNECT4
+    gi = _lib.game_info(game)
+    eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)
+    eng.load_weights(W.flatten(W.init_weights(gi.C, 16, 4, 16, gi.A, seed=2)))
+    rng = np.random.RandomState(1)
+    b, pl = boards_for(game, rng, 3000)
+    st = _lib.pack_grid(game, b, pl)
+    v0, l0, p0 = eng.net_eval(states=st[:0])
+    assert v0.shape == (0,) and l0.shape == (0, gi.A) and p0.shape == (0, gi.A)
+    v, l, p = eng.net_eval(states=st)            # 3000 positions: 4 per wave
+    for i in (0, 1234, 2999):
+        v1, l1, p1 = eng.net_eval(states=st[i:i + 1])   # 1 per wave
+        assert v1[0] == v[i] and np.array_equal(l1[0], l[i]) and np.array_equal(p1[0], p[i])
+    v2, l2, p2 = eng.net_eval(states=st[:1500])  # 2 per wave
+    assert np.array_equal(v2, v[:1500]) and np.array_equal(l2, l[:1500]) and np.array_equal(p2, p[:1500])
+    eng.close()
