@@ -258,3 +258,29 @@ def test_dragonchess_interface(golden_dir):
     assert k.LegalActions()[cls.move_to_int["27 36"]] == 1
     k.ApplyAction(cls.move_to_int["27 36"])
     assert k.Winner() == 1
+
+
+def test_generate_training_samples_dragonchess(tmp_path, monkeypatch):
+    """The drop-in path for the wide game: compact child lists scattered to the 4032-wide pi, 17-plane boards, the
+    int8-wrapped policy dim of the reference's blobs (4032 -> -64, Blackbird.py:76-79), one PutGames per game."""
+    monkeypatch.chdir(tmp_path)
+    from blackbird_amd import Blackbird, DragonChess, proto_wire
+    cfg = {"blocks": 1, "filters": 16, "eval": {"dense": 16}, "hasTeacher": False,
+           "policy": {"dirichlet": {"alpha": 0.2, "epsilon": 0.3}}, "training": {"optimizer": "adam"}}
+    model = Blackbird.Model(DragonChess.BoardState, "dc", {"explorationRate": 0.85, "playLimit": 6}, cfg)
+    Blackbird.GenerateTrainingSamples(model, 3, 1.0)
+    blobs = model.Conn.GetGames(model.Name, model.Version)
+    assert len(blobs) >= 3 * 2
+    n_term = 0
+    for bts in blobs:
+        f = proto_wire.decode_state(bts)
+        assert np.frombuffer(f["boardDims"], dtype=np.int8).tolist() == [1, 8, 8, 17]
+        assert np.frombuffer(f["policyDims"], dtype=np.int8).tolist() == [np.int64(4032).astype(np.int8)]
+        pi = np.frombuffer(f["mctsPolicy"], dtype=np.float64)
+        board = np.frombuffer(f["boardEncoding"], dtype=np.int8)
+        assert pi.shape == (4032,) and board.shape == (8 * 8 * 17,)
+        if pi.any():
+            assert abs(pi.sum() - 1.0) < 1e-12 and (pi >= 0).all() and np.count_nonzero(pi) <= 6
+        else:
+            n_term += 1
+    assert n_term == 3  # one terminal example (pi = 0) per game
