@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["BB_MEGA_QUEUE"] = os.environ.get("QMODE", "1")
 import numpy as np
 from blackbird_amd import _lib, weights as W
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbb_stamps.so")
+_lib.LIB_PATH = os.path.abspath(os.environ.get("BB_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbb_stamps.so")))
 game = _lib.GAME_CONNECT4
 eng = _lib.Engine(game, n_slots=4096, sims_per_move=800, evaluator=_lib.EVAL_NET, noise_on=True, max_games=4096 * 12)
 eng.load_weights(W.flatten(W.init_weights(3, 16, 4, 16, 7, seed=0)))
