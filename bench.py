@@ -15,7 +15,8 @@ would start and finish in lock-step and a short timed window would see no comple
 
 N > 1: one process per GPU (torch.distributed, backend nccl == RCCL), disjoint game-id/RNG
 streams per rank, no collective in the data path; the (s, pi, z) examples of the timed region are
-all-gathered once after timing (the epoch-end exchange of SURVEY.md 8e).
+all-gathered once after timing (the epoch-end exchange of SURVEY.md 8e).  Under torch.distributed.run the ranks are
+what the launcher made them; `python bench.py --gpus N` without a launcher starts that same command itself.
 
 usage: python bench.py [--gpus N] [--steps K] [--warmup W]
 """
@@ -90,6 +91,18 @@ def main():
                     help="c2 = BASELINE configs[1] (default, the headline); c5 = the same game with the 20-block x "
                          "256-filter network of configs[4] (one ply is 3.3 M evaluations: use --steps 1 --warmup 0 --prefill 1)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started by hand for several GPUs: become the launcher (a child process, before anything touches a GPU) --
+        # the same command line the driver uses, one rank per GPU on this node
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

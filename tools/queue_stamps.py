@@ -19,7 +19,7 @@ eng.selfplay_step(3); eng.synchronize(); dt = time.time() - t0
 L.bb_debug_stamps(eng.h, st.ctypes.data)
 st = st.astype(np.float64)
 print(f"3 plies in {dt*1e3:.1f} ms")
-print(f"pairs {st[11]:.0f}"); print(f"net waves: busy {st[0]/st[1]:.3f}; cycles per evaluation {st[0]/st[15]:.0f}; evaluations {st[15]:.0f}")
+print(f"wave lifetimes (mean over waves, shader cycles / 2.4e6 = ms): network {st[1]/max(st[4],1)/2.4e6:.1f} ms, tree {st[3]/max(st[5],1)/2.4e6:.1f} ms of a {dt*1e3:.1f} ms run"); print(f"net waves: busy {st[0]/st[1]:.3f}; cycles per evaluation {st[0]/st[15]:.0f}; evaluations {st[15]:.0f}")
 print(f"tree waves: busy {st[2]/st[3]:.3f}; cycles per async call {st[2]/st[13]:.0f}; games per call {st[14]/st[13]:.2f}; calls {st[13]:.0f}")
 v = st[12]
 if v > 0 and os.environ.get("QMODE", "1") == "1":
