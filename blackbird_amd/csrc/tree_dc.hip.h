@@ -220,14 +220,41 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
 }
 
 __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int lane, double *lds) {
-    int leaf = d.pend_leaf[g];
+    // One wave per game and one wave per SIMD: this step is a chain of dependent HBM round trips (2-3 us each on
+    // these sparsely touched pools), so every word that does not depend on another load is requested up front, and
+    // the statistics the backup will update are fetched BEFORE the expansion, whose work then hides their latency.
+    const int leaf = d.pend_leaf[g];
+    const int pend_exp = d.pend_expand[g];
+    const float v = d.eval_value[g];
+    const int plen = d.path_len[g];
+    const int lid = d.game_lid[g];
+    const uint32_t *pn = d.path + (size_t)g * DragonChess::MAXPATH;
+    const uint32_t *pe = E.path_edge + (size_t)g * DragonChess::MAXPATH;
+    const uint32_t pn0 = pn[lane], pe0 = pe[lane]; // lane < 64 <= MAXPATH: in bounds whatever the path length
+    int root_n = 0, pp = 0;
+    float root_w = 0.f;
+    if (lane == 0) {
+        root_n = d.root_N[g];
+        pp = d.root_pp[g];
+        root_w = d.root_W[g];
+    }
     if (leaf < 0) return;
     DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
     DCNode *node = pool + leaf;
     DCState st = ((const DCState *)d.leaf_state)[g];
-    float v = d.eval_value[g];
-    if (d.pend_expand[g]) {
-        uint32_t gid = d.first_game_id + (uint32_t)d.game_lid[g];
+    // the path's statistics (edges and nodes above the leaf: the expansion below touches none of them)
+    const bool on_path = lane < plen;
+    DCNode *my_nd = pool + (on_path ? pn0 : 0u);
+    const size_t my_e = (size_t)g * E.edge_cap + (on_path ? (pe0 & 0x3FFFFFFFu) : 0u);
+    int my_n = 0, my_all = 0;
+    float my_w = 0.f;
+    if (on_path) {
+        my_n = E.N[my_e];
+        my_w = E.W[my_e];
+        my_all = my_nd->all;
+    }
+    if (pend_exp) {
+        uint32_t gid = d.first_game_id + (uint32_t)lid;
         if (!dc_expand(d, E, g, node, st, ((const DCState *)d.leaf_state)[g].b, d.eval_policy + (size_t)g * 4032, gid, lane, lds) && lane == 0)
             d.ctr[(size_t)g * 8 + 6] += 1;
     }
@@ -243,10 +270,17 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
 #ifdef BB_STAMPS
     long long b0 = clock64();
 #endif
-    int plen = d.path_len[g];
-    const uint32_t *pn = d.path + (size_t)g * DragonChess::MAXPATH;
-    const uint32_t *pe = E.path_edge + (size_t)g * DragonChess::MAXPATH;
-    for (int k = lane; k < plen; k += 64) {
+    if (on_path) {
+        int pl = (int)(pe0 >> 30);
+        int n = my_n + 1, all = my_all + 1;
+        float w = my_w + ((pl == prev) ? v01 : vflip);
+        E.N[my_e] = n;
+        E.W[my_e] = w;
+        E.Q[my_e] = __fdiv_rn(w, (float)n);
+        my_nd->all = all;
+        my_nd->sq = __dsqrt_rn(1.0 + (double)all);
+    }
+    for (int k = 64 + lane; k < plen; k += 64) { // paths beyond 64 edges (not seen at 400 simulations)
         DCNode *nd = pool + pn[k];
         uint32_t ew = pe[k];
         int pl = (int)(ew >> 30);
@@ -260,9 +294,8 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
         nd->sq = __dsqrt_rn(1.0 + (double)all);
     }
     if (lane == 0) {
-        d.root_N[g] += 1;
-        int pp = d.root_pp[g];
-        if (pp) d.root_W[g] += (pp == prev) ? v01 : vflip;
+        d.root_N[g] = root_n + 1;
+        if (pp) d.root_W[g] = root_w + ((pp == prev) ? v01 : vflip);
         d.pend_leaf[g] = -1;
     }
 #ifdef BB_STAMPS
@@ -297,12 +330,25 @@ __device__ __forceinline__ int dc_create_child(const TreeDev &d, const DCEdges &
 }
 
 __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int lane, double *lds) {
-    if (d.game_lid[g] < 0 || d.sims_left[g] <= 0) return;
+    const int lid = d.game_lid[g], sims_left = d.sims_left[g];
+    int cur = d.root[g];
+    int nn = d.n_nodes[g];
+    // the counters the tail updates, requested with the first round of loads instead of after the descent
+    int t_serial = 0;
+    uint64_t t_evals = 0, t_c0 = 0, t_c1 = 0, t_c3 = 0, t_c6 = 0;
+    uint64_t *ctr = d.ctr + (size_t)g * 8;
+    if (lane == 0) {
+        t_serial = d.sim_serial[g];
+        t_evals = d.evals[g];
+        t_c0 = ctr[0];
+        t_c1 = ctr[1];
+        t_c3 = ctr[3];
+        t_c6 = ctr[6];
+    }
+    if (lid < 0 || sims_left <= 0) return;
     DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
     uint32_t *pn = d.path + (size_t)g * DragonChess::MAXPATH;
     uint32_t *pe = E.path_edge + (size_t)g * DragonChess::MAXPATH;
-    int cur = d.root[g];
-    int nn = d.n_nodes[g];
     int depth = 0, expand = 0, overflow = 0, term_leaf = 0;
     const bool inline_expand = d.priors_ones != 0;
     const bool fixed = d.kind == 1, rollout = d.evaluator == 2;
@@ -375,19 +421,18 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
     }
     if (lane == 0) {
         ((DCState *)d.leaf_state)[g] = st;
-        d.leaf_game_id[g] = d.first_game_id + (uint32_t)d.game_lid[g];
+        d.leaf_game_id[g] = d.first_game_id + (uint32_t)lid;
         d.leaf_serial[g] = cur;
         d.pend_leaf[g] = cur;
         d.pend_expand[g] = expand;
         d.path_len[g] = depth;
-        d.sims_left[g] -= 1;
-        d.sim_serial[g] += 1;
-        d.evals[g] += 1;
-        uint64_t *c = d.ctr + (size_t)g * 8;
-        c[0] += 1;
-        c[1] += (uint64_t)depth;
-        c[3] += (uint64_t)term_leaf;
-        c[6] += (uint64_t)overflow;
+        d.sims_left[g] = sims_left - 1;
+        d.sim_serial[g] = t_serial + 1;
+        d.evals[g] = t_evals + 1;
+        ctr[0] = t_c0 + 1;
+        ctr[1] = t_c1 + (uint64_t)depth;
+        ctr[3] = t_c3 + (uint64_t)term_leaf;
+        ctr[6] = t_c6 + (uint64_t)overflow;
     }
 }
 
