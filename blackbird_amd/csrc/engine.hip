@@ -273,9 +273,7 @@ static int engine_alloc(bb_engine *e) {
         DCEdges &E = e->edges;
         E.edge_cap = d.node_cap * 24; // ~15-25 legal moves per position; overflow is counted, never silent
         size_t ne = n * (size_t)E.edge_cap;
-        if (dalloc(e, E.act, ne, false) || dalloc(e, E.N, ne, false) || dalloc(e, E.Q, ne, false) ||
-            dalloc(e, E.W, ne, false) || dalloc(e, E.child, ne, false) || dalloc(e, E.cP, ne, false) ||
-            dalloc(e, E.used, n) || dalloc(e, E.path_edge, n * G::MAXPATH))
+        if (dalloc(e, E.e, ne, false) || dalloc(e, E.used, n) || dalloc(e, E.path_edge, n * G::MAXPATH))
             return BB_ERR_HIP;
         E.noise_on = c.noise_on;
         E.alpha = c.alpha;

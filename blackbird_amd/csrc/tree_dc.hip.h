@@ -24,12 +24,23 @@ struct alignas(128) DCNode {
 };
 static_assert(sizeof(DCNode) == 128, "DragonChess node row is one 128-byte line");
 
-struct DCEdges { // per-slot SoA edge pool, stride edge_cap
-    uint16_t *act;
-    int32_t *N;
-    float *Q, *W;
-    int32_t *child;
-    double *cP;
+// One edge = one 32-byte record.  The lanes of a wave read the edges of a node as one contiguous run (2 x dwordx4
+// per lane), and a level of the descent touches ONE page of the game's edge pool instead of one page in each of six
+// per-field pools -- on these sparsely touched multi-GB pools every extra page is an address-translation miss.
+struct alignas(16) DCEdge {
+    int32_t N;      // child.Plays
+    float Q;        // child.Value / child.Plays (float32), 0 when unvisited
+    float W;        // child.Value
+    int32_t child;  // node index | CHILD_TERM_BIT, or CHILD_NONE
+    double cP;      // c_puct * prior
+    uint16_t act;   // action id
+    uint16_t pad0;
+    uint32_t pad1;
+};
+static_assert(sizeof(DCEdge) == 32, "DragonChess edge record is half a cache line");
+
+struct DCEdges { // per-slot edge pool, stride edge_cap
+    DCEdge *e;
     int32_t *used; // [n_slots] allocation cursor
     uint32_t *path_edge; // [n_slots][MAXPATH] absolute edge index | player << 30
     int edge_cap;
@@ -193,12 +204,12 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
     for (int i = 0; i < MPL; i++)
         if (mya[i] >= 0) {
             size_t e = base + lane + 64 * i;
-            E.act[e] = (uint16_t)mya[i];
-            E.N[e] = 0;
-            E.Q[e] = 0.f;
-            E.W[e] = 0.f;
-            E.child[e] = CHILD_NONE;
-            E.cP[e] = policy ? d.c_puct * __ddiv_rn((double)myp[i], tot) : d.c_puct * 1.0;
+            E.e[e].act = (uint16_t)mya[i];
+            E.e[e].N = 0;
+            E.e[e].Q = 0.f;
+            E.e[e].W = 0.f;
+            E.e[e].child = CHILD_NONE;
+            E.e[e].cP = policy ? d.c_puct * __ddiv_rn((double)myp[i], tot) : d.c_puct * 1.0;
         }
     if (lane == 0) {
         node->flags |= NODE_EXPANDED;
@@ -249,8 +260,8 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
     int my_n = 0, my_all = 0;
     float my_w = 0.f;
     if (on_path) {
-        my_n = E.N[my_e];
-        my_w = E.W[my_e];
+        my_n = E.e[my_e].N;
+        my_w = E.e[my_e].W;
         my_all = my_nd->all;
     }
     if (pend_exp) {
@@ -274,9 +285,9 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
         int pl = (int)(pe0 >> 30);
         int n = my_n + 1, all = my_all + 1;
         float w = my_w + ((pl == prev) ? v01 : vflip);
-        E.N[my_e] = n;
-        E.W[my_e] = w;
-        E.Q[my_e] = __fdiv_rn(w, (float)n);
+        E.e[my_e].N = n;
+        E.e[my_e].W = w;
+        E.e[my_e].Q = __fdiv_rn(w, (float)n);
         my_nd->all = all;
         my_nd->sq = __dsqrt_rn(1.0 + (double)all);
     }
@@ -285,11 +296,11 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
         uint32_t ew = pe[k];
         int pl = (int)(ew >> 30);
         size_t e = (size_t)g * E.edge_cap + (ew & 0x3FFFFFFFu);
-        int n = E.N[e] + 1, all = nd->all + 1;
-        float w = E.W[e] + ((pl == prev) ? v01 : vflip);
-        E.N[e] = n;
-        E.W[e] = w;
-        E.Q[e] = __fdiv_rn(w, (float)n);
+        int n = E.e[e].N + 1, all = nd->all + 1;
+        float w = E.e[e].W + ((pl == prev) ? v01 : vflip);
+        E.e[e].N = n;
+        E.e[e].W = w;
+        E.e[e].Q = __fdiv_rn(w, (float)n);
         nd->all = all;
         nd->sq = __dsqrt_rn(1.0 + (double)all);
     }
@@ -322,9 +333,8 @@ __device__ __forceinline__ int dc_create_child(const TreeDev &d, const DCEdges &
         c->edge_off = 0;
         c->all = 0;
         c->serial = idx;
-        E.child[e] = word;
-        d.n_nodes[g] = idx + 1;
-        d.ctr[(size_t)g * 8 + 2] += 1;
+        E.e[e].child = word;
+        // (n_nodes[g] and the node counter are written once by the caller's tail: nn carries the new count)
     }
     return word;
 }
@@ -333,19 +343,28 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
     const int lid = d.game_lid[g], sims_left = d.sims_left[g];
     int cur = d.root[g];
     int nn = d.n_nodes[g];
+    const int nn0 = nn;
     // the counters the tail updates, requested with the first round of loads instead of after the descent
     int t_serial = 0;
-    uint64_t t_evals = 0, t_c0 = 0, t_c1 = 0, t_c3 = 0, t_c6 = 0;
+    uint64_t t_evals = 0, t_c0 = 0, t_c1 = 0, t_c2 = 0, t_c3 = 0, t_c6 = 0;
     uint64_t *ctr = d.ctr + (size_t)g * 8;
     if (lane == 0) {
         t_serial = d.sim_serial[g];
         t_evals = d.evals[g];
         t_c0 = ctr[0];
         t_c1 = ctr[1];
+        t_c2 = ctr[2];
         t_c3 = ctr[3];
         t_c6 = ctr[6];
     }
     if (lid < 0 || sims_left <= 0) return;
+#ifdef BB_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    long long q0 = clock64(), q_pre = 0, q_hdr = 0, q_edge = 0, q_cmp = 0, q_rest = 0, q_lv = 0;
+#define QS(acc) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); long long _q = clock64(); acc += _q - q0; q0 = _q; } while (0)
+#else
+#define QS(acc) do {} while (0)
+#endif
     DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
     uint32_t *pn = d.path + (size_t)g * DragonChess::MAXPATH;
     uint32_t *pe = E.path_edge + (size_t)g * DragonChess::MAXPATH;
@@ -355,6 +374,7 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
     DCState st;
     int flags = 0;
     bool have = false;
+    uint32_t my_pn = 0, my_pe = 0;
     for (int it = 0;; it++) {
         DCNode *node = pool + cur;
         if (!have) {
@@ -362,6 +382,12 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
         }
         int n_edges = node->n_edges, edge_off = node->edge_off;
         double sq = node->sq;
+#ifdef BB_STAMPS
+        asm volatile("" ::"v"(n_edges), "v"(edge_off), "v"(sq), "v"(flags));
+        if (it == 0) QS(q_pre); else QS(q_rest);
+        q_lv++;
+        QS(q_hdr);
+#endif
         bool have_st = have;
         have = false;
         if (fixed && it >= d.max_depth) {
@@ -387,24 +413,41 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
         double bu = -1.0;
         int bi = -1, bchild = CHILD_NONE, bact = 0;
         size_t base = (size_t)g * E.edge_cap + edge_off;
+#ifdef BB_STAMPS
+        if (lane < n_edges) {
+            DCEdge probe = E.e[base + lane];
+            asm volatile("" ::"v"(probe.N), "v"(probe.cP));
+        }
+        QS(q_edge);
+#endif
         for (int k = lane; k < n_edges; k += 64) {
             size_t e = base + k;
-            int Ni = E.N[e];
-            double q = child_q(d, E.Q[e], rollout ? E.W[e] : 0.f, Ni);
-            double u = puct_score(q, E.cP[e], sq, Ni, true);
+            int Ni = E.e[e].N;
+            double q = child_q(d, E.e[e].Q, rollout ? E.e[e].W : 0.f, Ni);
+            double u = puct_score(q, E.e[e].cP, sq, Ni, true);
             if (bi < 0 || u > bu) {
                 bu = u;
                 bi = k;
-                bchild = E.child[e];
-                bact = E.act[e];
+                bchild = E.e[e].child;
+                bact = E.e[e].act;
             }
         }
         wave_argmax(bu, bi, bchild, bact);
+        QS(q_cmp);
         if (depth >= DragonChess::MAXPATH) { overflow = 1; if (!have_st) st = node->st; break; }
         int child = bchild;
-        if (lane == 0) {
-            pn[depth] = (uint32_t)cur;
-            pe[depth] = (uint32_t)(edge_off + bi) | ((uint32_t)((flags >> 4) & 3) << 30);
+        { // the path stays in registers (lane k <-> depth k) until the descent is over: a store per level would put
+          // a write acknowledgement in front of every following load (vmcnt counts both, in order)
+            const uint32_t pnv = (uint32_t)cur, pev = (uint32_t)(edge_off + bi) | ((uint32_t)((flags >> 4) & 3) << 30);
+            if (depth < 64) {
+                if (lane == depth) {
+                    my_pn = pnv;
+                    my_pe = pev;
+                }
+            } else if (lane == 0) {
+                pn[depth] = pnv;
+                pe[depth] = pev;
+            }
         }
         if (child == CHILD_NONE) {
             DCState pst = node->st, st2;
@@ -419,6 +462,10 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
         depth++;
         cur = child & ~CHILD_TERM_BIT;
     }
+    if (lane < depth) { // (depth <= 64 here; deeper entries were stored as they came)
+        pn[lane] = my_pn;
+        pe[lane] = my_pe;
+    }
     if (lane == 0) {
         ((DCState *)d.leaf_state)[g] = st;
         d.leaf_game_id[g] = d.first_game_id + (uint32_t)lid;
@@ -431,9 +478,25 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
         d.evals[g] = t_evals + 1;
         ctr[0] = t_c0 + 1;
         ctr[1] = t_c1 + (uint64_t)depth;
+        if (nn != nn0) {
+            d.n_nodes[g] = nn;
+            ctr[2] = t_c2 + (uint64_t)(nn - nn0);
+        }
         ctr[3] = t_c3 + (uint64_t)term_leaf;
         ctr[6] = t_c6 + (uint64_t)overflow;
     }
+#ifdef BB_STAMPS
+    QS(q_rest);
+    if (lane == 0 && d.stamps) {
+        atomicAdd(&d.stamps[11], (unsigned long long)q_pre);
+        atomicAdd(&d.stamps[12], (unsigned long long)q_hdr);
+        atomicAdd(&d.stamps[13], (unsigned long long)q_edge);
+        atomicAdd(&d.stamps[14], (unsigned long long)q_cmp);
+        atomicAdd(&d.stamps[15], (unsigned long long)q_rest);
+        atomicAdd(&d.stamps[1], (unsigned long long)q_lv);
+    }
+#endif
+#undef QS
 }
 
 #define DC_LDS_DOUBLES 4032
@@ -477,22 +540,22 @@ __device__ int dc_choose_move(const TreeDev &d, const DCEdges &E, int g, int lan
     if (lane == 0 && (node->flags & NODE_EXPANDED)) {
         int n = node->n_edges;
         size_t base = (size_t)g * E.edge_cap + node->edge_off;
-        for (int k = 0; k < n; k++) tot += E.N[base + k];
+        for (int k = 0; k < n; k++) tot += E.e[base + k].N;
         if (temp == 0.0) {
             double bu = -1.0;
             for (int k = 0; k < n; k++) {
-                int Ni = E.N[base + k];
-                double uu = puct_score(child_q(d, E.Q[base + k], E.W[base + k], Ni), E.cP[base + k], node->sq, Ni, true);
+                int Ni = E.e[base + k].N;
+                double uu = puct_score(child_q(d, E.e[base + k].Q, E.e[base + k].W, Ni), E.e[base + k].cP, node->sq, Ni, true);
                 if (eo < 0 || uu > bu) {
                     bu = uu;
                     eo = k;
                 }
             }
-            act = n > 0 ? (int)E.act[base + eo] : -4;
+            act = n > 0 ? (int)E.e[base + eo].act : -4;
         } else {
             double it = 1.0 / temp, allp = 0.0;
             for (int k = 0; k < n; k++) {
-                double c = (double)E.N[base + k];
+                double c = (double)E.e[base + k].N;
                 allp += (it == 1.0) ? c : pow(c, it);
             }
             if (!(allp > 0.0)) {
@@ -500,20 +563,20 @@ __device__ int dc_choose_move(const TreeDev &d, const DCEdges &E, int g, int lan
             } else {
                 double last = 0.0;
                 for (int k = 0; k < n; k++) {
-                    double c = (double)E.N[base + k];
+                    double c = (double)E.e[base + k].N;
                     last += __ddiv_rn((it == 1.0) ? c : pow(c, it), allp);
                 }
                 double run = 0.0;
                 eo = n - 1;
                 for (int k = 0; k < n; k++) {
-                    double c = (double)E.N[base + k];
+                    double c = (double)E.e[base + k].N;
                     run += __ddiv_rn((it == 1.0) ? c : pow(c, it), allp);
                     if (__ddiv_rn(run, last) > u) {
                         eo = k;
                         break;
                     }
                 }
-                act = (int)E.act[base + eo];
+                act = (int)E.e[base + eo].act;
             }
         }
     }
@@ -542,9 +605,9 @@ __global__ void __launch_bounds__(256) k_dc_sample(TreeDev d, DCEdges E, double 
     if (node->flags & NODE_EXPANDED) {
         size_t base = (size_t)g * E.edge_cap + node->edge_off;
         for (int k = lane; k < node->n_edges; k += 64) {
-            if (d.out_child_plays) d.out_child_plays[(size_t)g * S + k] = E.N[base + k];
-            if (d.out_child_value) d.out_child_value[(size_t)g * S + k] = E.W[base + k];
-            if (out_child_action) out_child_action[(size_t)g * S + k] = E.act[base + k];
+            if (d.out_child_plays) d.out_child_plays[(size_t)g * S + k] = E.e[base + k].N;
+            if (d.out_child_value) d.out_child_value[(size_t)g * S + k] = E.e[base + k].W;
+            if (out_child_action) out_child_action[(size_t)g * S + k] = E.e[base + k].act;
         }
     }
     if (lane == 0) {
@@ -595,7 +658,7 @@ __device__ void dc_advance_root(const TreeDev &d, const DCEdges &E, int g, int l
     size_t base = (size_t)g * E.edge_cap + node->edge_off;
     int k = -1;
     for (int i = lane; i < n; i += 64)
-        if ((int)E.act[base + i] == action) k = i;
+        if ((int)E.e[base + i].act == action) k = i;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) k = max(k, __shfl_xor(k, o, 64));
     if (k < 0) { // not a legal move of the root: leave the tree alone (the next FindMove asserts)
@@ -603,8 +666,8 @@ __device__ void dc_advance_root(const TreeDev &d, const DCEdges &E, int g, int l
         return;
     }
     size_t e = base + k;
-    int child = E.child[e], cn = E.N[e];
-    float cw = E.W[e];
+    int child = E.e[e].child, cn = E.e[e].N;
+    float cw = E.e[e].W;
     if (child == CHILD_NONE) {
         bool terminal;
         int nn = d.n_nodes[g];
@@ -617,6 +680,10 @@ __device__ void dc_advance_root(const TreeDev &d, const DCEdges &E, int g, int l
                 d.ctr[(size_t)g * 8 + 6] += 1;
             }
             return;
+        }
+        if (lane == 0) {
+            d.n_nodes[g] = nn;
+            d.ctr[(size_t)g * 8 + 2] += 1;
         }
     } else {
         new_st = pool[child & ~CHILD_TERM_BIT].st;
@@ -677,8 +744,8 @@ __device__ void dc_write_example(const TreeDev &d, const DCEdges &E, int lid, in
     int n = terminal_example ? 0 : node->n_edges;
     size_t base = terminal_example ? 0 : (size_t)g * E.edge_cap + node->edge_off;
     for (int k = lane; k < S; k += 64) {
-        vis[k] = k < n ? (uint32_t)E.N[base + k] : 0u;
-        act[k] = k < n ? E.act[base + k] : (uint16_t)0xFFFF;
+        vis[k] = k < n ? (uint32_t)E.e[base + k].N : 0u;
+        act[k] = k < n ? E.e[base + k].act : (uint16_t)0xFFFF;
     }
     if (lane == 0) {
         ExampleHdr h;
