@@ -215,7 +215,7 @@ def main():
                                    % (args.slots, blocks, filters, 4 if args.workload == "c5" else 1),
                        "game": "Connect4", "sims_per_move": args.sims, "concurrent_games_per_gpu": args.slots,
                        "blocks": blocks, "filters": filters, "step": "800 tree+network rounds over all games (one ply in lock-step terms)",
-                       "launch_structure": ["lockstep", "async-rounds", "persistent-phases", "persistent-queue", "persistent-teams"][mode],
+                       "launch_structure": ["lockstep", "async-rounds", "persistent-phases", "persistent-queue", "persistent-teams", "wave-per-game"][mode],
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
             "node_evals_per_sec": sims / dt, "net_evals_per_sec_rank0": cnt["evals"] / dt, "plies_per_sec": plies / dt,
             "games_finished": games, "examples_fetched": int(len(rec_t)), "examples_fetch_s": fetch_s, "terminal_leaf_fraction": cnt["terminal_leaves"] / max(cnt["sims"], 1),

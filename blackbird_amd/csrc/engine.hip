@@ -11,6 +11,7 @@
 #include "mega.hip.h"
 #include "mega2.hip.h"
 #include "mega3.hip.h"
+#include "mega_dc.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -211,6 +212,7 @@ struct bb_engine {
     bool mega = false; // persistent per-CU self-play kernel (mega.hip.h)
     int mega_queue = 0; // 1 work-queue kernel (mega2.hip.h), 2 work queue + network teams (mega3.hip.h)
     bool async_selfplay = false; // dense games, DynamicMCTS, deterministic evaluators: k_tree_async rounds
+    bool dc_fused = false;       // DragonChess, DynamicMCTS, 16-filter network: one wave keeps its game for a whole launch (mega_dc.hip.h)
     int round = 0;
     int time_every = 0;
     uint64_t eval_launches = 0;
@@ -258,7 +260,7 @@ static int engine_alloc(bb_engine *e) {
         dalloc(e, d.eval_policy, n * PSTRIDE) || dalloc(e, d.ctr, n * 8) || dalloc(e, d.evals, n) || dalloc(e, d.out_action, n) ||
         dalloc(e, d.out_root_plays, n) || dalloc(e, d.out_child_plays, n * G::S) ||
         dalloc(e, d.out_root_winrate, n) || dalloc(e, d.out_child_value, n * G::S) || dalloc(e, e->d_u, n) ||
-        dalloc(e, e->d_actions, n) || dalloc(e, d.stamps, 16) || dalloc(e, d.resume_cur, n) ||
+        dalloc(e, e->d_actions, n) || dalloc(e, d.stamps, 16 * 64) || dalloc(e, d.resume_cur, n) ||
         dalloc(e, d.resume_depth, n) || dalloc(e, d.post_count, 8) || dalloc(e, d.post_slot, n) ||
         dalloc(e, e->d_eval_noise, n * G::S))
         return BB_ERR_HIP;
@@ -371,6 +373,8 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     e->mega = e->async_selfplay && cfg->evaluator == BB_EVAL_NET;
     if (const char *env = getenv("BB_MEGA")) e->mega = e->mega && atoi(env) != 0;
     e->mega_queue = e->mega ? 1 : 0; // default persistent kernel: the work-queue variant
+    e->dc_fused = cfg->game == BB_GAME_DRAGONCHESS && cfg->mcts_kind == BB_MCTS_DYNAMIC && cfg->evaluator == BB_EVAL_NET;
+    if (const char *env = getenv("BB_MEGA")) e->dc_fused = e->dc_fused && atoi(env) != 0;
     if (const char *env = getenv("BB_MEGA_QUEUE")) e->mega_queue = e->mega ? atoi(env) : 0; // 1 work queue, 2 work queue + network teams
     if (const char *env = getenv("BB_TREE_GPW")) {
         int v = atoi(env);
@@ -447,6 +451,7 @@ extern "C" int bb_selfplay_mode(bb_engine *e) {
     // the persistent kernels carry a 16-filter network of at most MEGA_RMAX blocks in LDS; anything else runs as rounds
     const bool fits = !e->has_weights || (!e->general_net && e->net.R <= MEGA_RMAX && e->net.head_floats <= MEGA_HEAD_FLOATS);
     if (e->mega && fits) return e->mega_queue == 2 ? 4 : (e->mega_queue == 1 ? 3 : 2);
+    if (e->dc_fused && (!e->has_weights || !e->general_net)) return 5;
     return e->async_selfplay ? 1 : 0;
 }
 
@@ -1116,6 +1121,24 @@ extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
     HIPCHK(hipSetDevice(e->cfg.device));
     GAME_SWITCH(e->cfg.game, {
         if (e->async_selfplay) return selfplay_rounds_async<G>(e, plies * e->sims_now);
+        if constexpr (G::GID == BB_GAME_DRAGONCHESS) {
+            if (e->dc_fused && e->has_weights && !e->general_net) {
+                // at most 16 plies per launch (a launch is plies x sims x ~70 us long; nothing inside can spin)
+                for (int done = 0; done < plies; done += 16) {
+                    const int now = plies - done < 16 ? plies - done : 16;
+                    bool timed = e->time_every > 0 && e->ev_used + 2 <= e->ev_pool.size();
+                    if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
+                    k_dc_selfplay_fused<<<nblk((size_t)e->dev.n_slots * 64), 256, 0, e->stream>>>(e->dev, e->edges, e->net, now, e->sims_now,
+                                                                                                  e->cfg.noise_on);
+                    HIPCHK(hipGetLastError());
+                    if (timed) {
+                        HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
+                        e->ev_used += 2;
+                    }
+                }
+                return BB_OK;
+            }
+        }
         for (int p = 0; p < plies; p++) {
             int rc = run_sims<G>(e, e->sims_now);
             if (rc) return rc;
@@ -1252,8 +1275,8 @@ extern "C" int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, dou
 // diagnostic builds only: point the stamp buffer at host-coherent memory so that it can be read while a kernel runs
 extern "C" int bb_debug_host_stamps(bb_engine *e, unsigned long long **host_out) {
     unsigned long long *p = nullptr;
-    HIPCHK(hipHostMalloc((void **)&p, 128, hipHostMallocCoherent | hipHostMallocMapped));
-    memset(p, 0, 128);
+    HIPCHK(hipHostMalloc((void **)&p, 16 * 64 * 8, hipHostMallocCoherent | hipHostMallocMapped));
+    memset(p, 0, 16 * 64 * 8);
     e->dev.stamps = p;
     for (int v = 0; v < 2; v++) e->view[v].stamps = p;
     *host_out = p;
@@ -1270,8 +1293,13 @@ extern "C" int bb_stream_done(bb_engine *e) { return hipStreamQuery(e->stream) =
 // diagnostic builds only (tools/): in-kernel cycle stamps accumulated by the tree / persistent kernels
 extern "C" int bb_debug_stamps(bb_engine *e, unsigned long long *out8) {
     HIPCHK(sync_all(e));
-    HIPCHK(hipMemcpy(out8, e->dev.stamps, 128, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(e->dev.stamps, 0, 128));
+    unsigned long long all[16 * 64]; // 64 copies (the DragonChess kernels spread their flushes), summed here
+    HIPCHK(hipMemcpy(all, e->dev.stamps, sizeof(all), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 16; i++) {
+        out8[i] = 0;
+        for (int c = 0; c < 64; c++) out8[i] += all[c * 16 + i];
+    }
+    HIPCHK(hipMemset(e->dev.stamps, 0, sizeof(all)));
     return BB_OK;
 }
 #endif

@@ -1,0 +1,55 @@
+// mega_dc.hip.h -- DragonChess self-play with one wave per game for a whole launch.
+//
+// In the launch-per-simulation structure every game waits twice per simulation for the slowest of the 1024 waves
+// (the tree step lasts as long as the deepest descent: 63 us for a mean of 31 us of work per game; the network
+// kernel likewise), and every launch starts its code cold.  The games share nothing, so here a wave simply keeps
+// its game: apply -> select -> the network for its own leaf (the same net_body, one position, weights streamed from
+// L2) -> ..., then the move, for `plies` plies.  No wave ever waits for another one, so there is nothing to spin on:
+// every loop is bounded by plies x sims.  Per game this is exactly the lock-step sequence of operations, so the
+// results are identical (tests/test_gpu_mcts.py compares both with the oracle).
+#pragma once
+#include "net.hip.h"
+#include "tree_dc.hip.h"
+
+// The three phases are separate functions on purpose: inlined into one loop body the compiler keeps every phase's
+// address arithmetic alive across the others (256 VGPRs + 402 spilled, slower than the launches it replaces).
+__device__ __attribute__((noinline)) void dc_fused_tree(const TreeDev &d, const DCEdges &E, int g, int lane, double *tl) {
+    dc_phase_apply(d, E, g, lane, tl);
+    __threadfence_block();
+    dc_phase_select(d, E, g, lane, tl);
+    __threadfence_block();
+}
+__device__ __attribute__((noinline)) void dc_fused_net(const NetDev &nd, const TreeDev &d, const int *slot, float *nl, int noise_on) {
+    net_body<DragonChess, 1>(nd, 1, 0, slot, nl, (const DCState *)d.leaf_state, nullptr, d.leaf_game_id, d.leaf_serial, noise_on,
+                             d.eval_value, nullptr, d.eval_policy, DragonChess::A);
+    __threadfence_block();
+}
+__device__ __attribute__((noinline)) void dc_fused_move(const TreeDev &d, const DCEdges &E, int g, int lane, double *tl) {
+    dc_selfplay_move_body(d, E, g, lane, tl);
+    __threadfence_block();
+}
+
+__global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d, DCEdges E, NetDev nd, int plies, int sims, int noise_on) {
+    using NG = NetGeom<DragonChess, 1>;
+    // the tree's scratch (the 4032-double policy image) and the network's activations are never live together
+    constexpr int TREE_BYTES = DC_LDS_DOUBLES * 8, NET_BYTES = NG::WAVE_FLOATS * 4;
+    constexpr int WAVE_BYTES = ((TREE_BYTES > NET_BYTES ? TREE_BYTES : NET_BYTES) + 15) / 16 * 16;
+    static_assert(4 * WAVE_BYTES + 64 <= 163840, "four waves' scratch must fit the 160 KiB LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4][WAVE_BYTES];
+    __shared__ int myslot[4];
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (g >= d.n_slots) return;
+    double *tl = (double *)lds_all[wv];
+    float *nl = (float *)lds_all[wv];
+    if (lane == 0) myslot[wv] = g;
+    __threadfence_block();
+    for (int p = 0; p < plies; p++) {
+        if (d.game_lid[g] < 0) return; // this slot has played its last game
+        for (int s = 0; s < sims; s++) {
+            dc_fused_tree(d, E, g, lane, tl);
+            if (d.pend_leaf[g] >= 0) // (uniform) a leaf was posted: evaluate it right here
+                dc_fused_net(nd, d, &myslot[wv], nl, noise_on);
+        }
+        dc_fused_move(d, E, g, lane, tl);
+    }
+}

@@ -78,8 +78,10 @@ __device__ __forceinline__ float bb_beta_pair(uint64_t key, uint32_t game_id, ui
     for (int h = 1; h >= 0; h--) {
         float u = ((float)(r.x[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
         float v = ((float)(r.x[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        // hardware exp2/log2 (v_exp_f32 / v_log_f32): ~1e-6 relative error, far below what a prior-noise draw needs
-        float X = __powf(u, ia), Y = __powf(v, ib);
+        // u^(1/a) = exp2(log2(u) / a) on the hardware transcendentals (v_log_f32 / v_exp_f32, ~1e-6 relative error:
+        // far below what a prior-noise draw needs).  NOT __powf: that is the full-precision library pow, several
+        // hundred instructions per call -- four of them per trial pair were most of the noise cost
+        float X = __builtin_amdgcn_exp2f(ia * __builtin_amdgcn_logf(u)), Y = __builtin_amdgcn_exp2f(ib * __builtin_amdgcn_logf(v));
         if (X + Y <= 1.0f && X + Y > 0.0f) out = X / (X + Y); // h = 0 (the earlier trial) is written last
     }
     return out;

@@ -48,6 +48,17 @@ struct DCEdges { // per-slot edge pool, stride edge_cap
     float alpha, eps;
 };
 
+#ifdef BB_STAMPS
+// diagnostic build: cycle stamps accumulate in the wave's LDS scratch (16 words past the 4032-double policy image) and
+// are flushed once when the kernel ends, spread over 64 copies -- atomics inside the timed sections would sit in front
+// of every later s_waitcnt and a thousand waves on one address serialise in L2
+#define DC_LDS_DOUBLES 4048
+#define DST(i, v) do { if (lane == 0) ((unsigned long long *)(lds + 4032))[i] += (unsigned long long)(v); } while (0)
+#else
+#define DC_LDS_DOUBLES 4032
+#define DST(i, v) do {} while (0)
+#endif
+
 // ---- wave (64 lanes) collectives ----------------------------------------------------------------------
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
@@ -138,8 +149,11 @@ __device__ __forceinline__ double dc_np_sum(const double *a, int lane) {
 // AddChildren for the node `node` (state st): move generation (lane = from-square), priors, edge rows.
 // policy == nullptr -> MCTS.GetPriors default (ones).  lds: 4032 doubles of scratch owned by this wave.
 // board_mem: the 64 board bytes of `st` in memory (one coalesced load instead of dynamic indexing into registers)
+// node_idx / node_flags / used: the node's index (== its serial), its flags before the expansion and the slot's edge
+// cursor, loaded by the caller along with its other first-round loads (used is advanced on success).
 __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *node, const DCState &st,
-                          const int8_t *board_mem, const float *policy, uint32_t gid, int lane, double *lds) {
+                          const int8_t *board_mem, const float *policy, uint32_t gid, int lane, double *lds,
+                          int node_idx, int node_flags, int &used) {
 #ifdef BB_STAMPS
     long long x0 = clock64();
 #endif
@@ -150,11 +164,11 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
     int cnt = bb_popc64(m);
     int pre = wave_excl_scan_i(cnt, lane);
     int total = wave_sum_i(cnt);
-    int off = E.used[g];
+    int off = used;
     if (off + total > E.edge_cap) return false;
 #ifdef BB_STAMPS
     long long e0 = clock64(), e1 = e0, e2 = e0;
-    if (lane == 0 && d.stamps && policy) atomicAdd(&d.stamps[9], (unsigned long long)(e0 - x0));
+    if (policy) DST(9, e0 - x0);
 #endif
     // The moves are dealt evenly over the lanes (move j of the from-square-major enumeration -> lane j & 63): one
     // policy load, one Beta draw and one edge per lane instead of a serial loop over the busiest square's moves.
@@ -186,7 +200,7 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
             if (mya[i] >= 0) {
                 float p = policy[mya[i]];
                 if (E.noise_on)
-                    p = (1.0f - E.eps) * p + E.eps * bb_beta_noise(d.seed, gid, (uint32_t)node->serial, (uint32_t)mya[i], E.alpha);
+                    p = (1.0f - E.eps) * p + E.eps * bb_beta_noise(d.seed, gid, (uint32_t)node_idx, (uint32_t)mya[i], E.alpha);
                 myp[i] = p;
                 lds[mya[i]] = (double)p; // float32 * float64 legal mask (1.0)
             }
@@ -212,19 +226,20 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
             E.e[e].cP = policy ? d.c_puct * __ddiv_rn((double)myp[i], tot) : d.c_puct * 1.0;
         }
     if (lane == 0) {
-        node->flags |= NODE_EXPANDED;
+        node->flags = node_flags | NODE_EXPANDED;
         node->n_edges = total;
         node->edge_off = off;
         node->all = 0;
         node->sq = 1.0;
         E.used[g] = off + total;
     }
+    used = off + total;
 #ifdef BB_STAMPS
-    if (lane == 0 && d.stamps && policy) {
-        atomicAdd(&d.stamps[5], (unsigned long long)(e1 - e0));
-        atomicAdd(&d.stamps[6], (unsigned long long)(e2 - e1));
-        atomicAdd(&d.stamps[7], (unsigned long long)(clock64() - e2));
-        atomicAdd(&d.stamps[8], 1ull);
+    if (policy) {
+        DST(5, e1 - e0);
+        DST(6, e2 - e1);
+        DST(7, clock64() - e2);
+        DST(8, 1);
     }
 #endif
     return true;
@@ -234,6 +249,9 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
     // One wave per game and one wave per SIMD: this step is a chain of dependent HBM round trips (2-3 us each on
     // these sparsely touched pools), so every word that does not depend on another load is requested up front, and
     // the statistics the backup will update are fetched BEFORE the expansion, whose work then hides their latency.
+#ifdef BB_STAMPS
+    const long long a_in = clock64();
+#endif
     const int leaf = d.pend_leaf[g];
     const int pend_exp = d.pend_expand[g];
     const float v = d.eval_value[g];
@@ -249,7 +267,12 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
         pp = d.root_pp[g];
         root_w = d.root_W[g];
     }
+    int used = E.used[g];
     if (leaf < 0) return;
+#ifdef BB_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long a_r1 = clock64();
+#endif
     DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
     DCNode *node = pool + leaf;
     DCState st = ((const DCState *)d.leaf_state)[g];
@@ -264,9 +287,19 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
         my_w = E.e[my_e].W;
         my_all = my_nd->all;
     }
+    const int leaf_flags = node->flags;
+#ifdef BB_STAMPS
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long a_r2 = clock64();
+        DST(3, a_r2 - a_r1);  // second round of loads
+        DST(10, a_r1 - a_in); // entry -> first round complete (tools/dc_stamps.py)
+    }
+#endif
     if (pend_exp) {
         uint32_t gid = d.first_game_id + (uint32_t)lid;
-        if (!dc_expand(d, E, g, node, st, ((const DCState *)d.leaf_state)[g].b, d.eval_policy + (size_t)g * 4032, gid, lane, lds) && lane == 0)
+        if (!dc_expand(d, E, g, node, st, ((const DCState *)d.leaf_state)[g].b, d.eval_policy + (size_t)g * 4032, gid, lane, lds, leaf,
+                       leaf_flags, used) && lane == 0)
             d.ctr[(size_t)g * 8 + 6] += 1;
     }
     int player = st.player, prev = st.prev;
@@ -310,7 +343,7 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
         d.pend_leaf[g] = -1;
     }
 #ifdef BB_STAMPS
-    if (lane == 0 && d.stamps) atomicAdd(&d.stamps[10], (unsigned long long)(clock64() - b0));
+    (void)b0;
 #endif
 }
 
@@ -344,6 +377,7 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
     int cur = d.root[g];
     int nn = d.n_nodes[g];
     const int nn0 = nn;
+    int used = E.used[g];
     // the counters the tail updates, requested with the first round of loads instead of after the descent
     int t_serial = 0;
     uint64_t t_evals = 0, t_c0 = 0, t_c1 = 0, t_c2 = 0, t_c3 = 0, t_c6 = 0;
@@ -398,7 +432,7 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
             if (!have_st) st = node->st;
             if (flags & NODE_TERMINAL) { term_leaf = 1; break; }
             if (!inline_expand) { expand = 1; break; }
-            if (!dc_expand(d, E, g, node, st, node->st.b, nullptr, 0u, lane, lds)) { overflow = 1; break; }
+            if (!dc_expand(d, E, g, node, st, node->st.b, nullptr, 0u, lane, lds, cur, flags, used)) { overflow = 1; break; }
             __threadfence_block();
             if (!fixed) break;
             n_edges = node->n_edges;
@@ -487,38 +521,39 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
     }
 #ifdef BB_STAMPS
     QS(q_rest);
-    if (lane == 0 && d.stamps) {
-        atomicAdd(&d.stamps[11], (unsigned long long)q_pre);
-        atomicAdd(&d.stamps[12], (unsigned long long)q_hdr);
-        atomicAdd(&d.stamps[13], (unsigned long long)q_edge);
-        atomicAdd(&d.stamps[14], (unsigned long long)q_cmp);
-        atomicAdd(&d.stamps[15], (unsigned long long)q_rest);
-        atomicAdd(&d.stamps[1], (unsigned long long)q_lv);
-    }
+    DST(11, q_pre);
+    DST(12, q_hdr);
+    DST(13, q_edge);
+    DST(14, q_cmp);
+    DST(15, q_rest);
+    DST(1, q_lv);
 #endif
 #undef QS
 }
 
-#define DC_LDS_DOUBLES 4032
 __global__ void __launch_bounds__(256) k_dc_tree_step(TreeDev d, DCEdges E) {
-    __shared__ double lds[4][DC_LDS_DOUBLES];
+    __shared__ double lds_all[4][DC_LDS_DOUBLES];
     int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (g >= d.n_slots) return;
+    double *lds = lds_all[wv];
 #ifdef BB_STAMPS
+    if (lane < 16) ((unsigned long long *)(lds + 4032))[lane] = 0;
+    __threadfence_block();
     long long t0 = clock64();
 #endif
-    dc_phase_apply(d, E, g, lane, lds[wv]);
+    dc_phase_apply(d, E, g, lane, lds);
 #ifdef BB_STAMPS
     long long t1 = clock64();
 #endif
     __threadfence_block();
-    dc_phase_select(d, E, g, lane, lds[wv]);
+    dc_phase_select(d, E, g, lane, lds);
 #ifdef BB_STAMPS
     long long t2 = clock64();
     if (lane == 0 && d.stamps) {
-        atomicAdd(&d.stamps[0], (unsigned long long)(t1 - t0));
-        atomicAdd(&d.stamps[2], (unsigned long long)(t2 - t1));
-        atomicAdd(&d.stamps[4], 1ull);
+        DST(0, t1 - t0);
+        DST(2, t2 - t1);
+        DST(4, 1);
+        for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[(size_t)(g & 63) * 16 + i], ((unsigned long long *)(lds + 4032))[i]);
     }
 #endif
 }
@@ -760,11 +795,10 @@ __device__ void dc_write_example(const TreeDev &d, const DCEdges &E, int lid, in
     }
 }
 
-__global__ void __launch_bounds__(256) k_dc_selfplay_move(TreeDev d, DCEdges E) {
-    __shared__ double lds[4][DC_LDS_DOUBLES];
-    int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (g >= d.n_slots) return;
-    dc_phase_apply(d, E, g, lane, lds[wv]);
+// GenerateTrainingSamples' loop body for one game (one wave): last result applied, move sampled, example written,
+// root advanced, game finished / slot handed to the next game (Blackbird.py:240-268)
+__device__ void dc_selfplay_move_body(const TreeDev &d, const DCEdges &E, int g, int lane, double *lds) {
+    dc_phase_apply(d, E, g, lane, lds);
     __threadfence_block();
     int lid = d.game_lid[g];
     if (lid < 0) return;
@@ -823,6 +857,13 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_move(TreeDev d, DCEdges E) 
             d.sims_left[g] = 0;
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_dc_selfplay_move(TreeDev d, DCEdges E) {
+    __shared__ double lds[4][DC_LDS_DOUBLES];
+    int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (g >= d.n_slots) return;
+    dc_selfplay_move_body(d, E, g, lane, lds[wv]);
 }
 
 // MCTS.SampleValue rollouts for DragonChess: one wave per leaf (lane = from-square), capped at 2048 plies

@@ -164,7 +164,8 @@ int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, double *ms_per
 /* Which launch structure bb_selfplay_step uses: 0 lock-step (one tree + one evaluator launch per
  * simulation), 1 asynchronous rounds, 2 persistent per-CU kernel in lock-step phases (tree + network waves in
  * one workgroup), 3 persistent per-CU kernel with a work queue between its tree and network waves (default for
- * networks that fit LDS), 4 work queue + teams of three network waves per evaluation (experimental). */
+ * networks that fit LDS), 4 work queue + teams of network waves per evaluation (experimental), 5 DragonChess with the
+ * 16-filter network: one wave keeps its game for a whole launch -- tree step, network and move in the same wave. */
 int bb_selfplay_mode(bb_engine *e);
 
 /* Network.getEvaluation + getPolicy for n positions (Network.py:48-64; graph NetworkFactory.py:22-183).

@@ -210,3 +210,60 @@ def test_dc_selfplay_vs_oracle(orc):
         assert np.array_equal(r["player"], o["player"]) and np.array_equal(r["z"].astype(np.float32), o["z"])
         assert np.array_equal(_lib.game_encode(game, np.ascontiguousarray(r["state"])), o["boards"])
     eng.close()
+
+
+def test_dc_selfplay_one_wave_per_game(orc, monkeypatch):
+    """DragonChess with the network evaluator: the default launch structure (one wave keeps its game for a whole launch,
+    tree step and network in the same wave: selfplay_mode 5) must give the examples of the launch-per-simulation
+    structure byte for byte, with and without prior noise, and -- noise off -- the oracle's search fed the GPU network's
+    outputs.  Ragged slot count (5 slots, 4 waves per workgroup) and slot reuse (7 games)."""
+    from blackbird_amd import weights as W
+    game = _lib.GAME_DRAGONCHESS
+    n_games, sims, cap = 7, 12, 20
+    flat = W.flatten(W.init_weights(17, 16, 2, 16, 4032, seed=5))
+
+    def run(mega, noise):
+        monkeypatch.setenv("BB_MEGA", mega)
+        eng = _lib.Engine(game, n_slots=5, sims_per_move=sims, evaluator=_lib.EVAL_NET, seed=7, max_games=n_games,
+                          max_plies=cap, noise_on=noise)
+        eng.load_weights(flat)
+        mode = eng.selfplay_mode()
+        eng.selfplay_begin(n_games, 1.0)
+        guard = 0
+        while not eng.selfplay_done()[0]:
+            eng.selfplay_step(3)
+            guard += 1
+            assert guard < 100
+        rec, offs, win = eng.fetch_examples()
+        assert eng.counters()["overflow"] == 0
+        eng.close()
+        return rec, offs, win, mode
+
+    for noise in (True, False):
+        a, b = run("1", noise), run("0", noise)
+        assert (a[3], b[3]) == (5, 0)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[0].tobytes() == b[0].tobytes(), noise
+    rec, offs, win, _m = a  # noise off
+    monkeypatch.delenv("BB_MEGA")
+    ev = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)
+    ev.load_weights(flat)
+
+    def cb(_ctx, stp, vp, pp):
+        v, _l, p = ev.net_eval(planes=orc.encode(orc.DC, stp.contents))
+        vp[0] = float(v[0])
+        if pp:
+            for i in range(4032):
+                pp[i] = float(p[0, i])
+
+    cfg = orc.make_cfg(orc.DC, evaluator=orc.EVAL_CALLBACK, seed=7, cb=orc.EVAL_CB(cb))
+    for gidx in range(n_games):
+        o = orc.selfplay_game(cfg, gidx, 1.0, sims, cap)
+        r = rec[offs[gidx]:offs[gidx + 1]]
+        assert len(r) == o["n"] and win[gidx] == o["winner"], gidx
+        for k in range(len(r)):
+            pi = np.zeros(4032)
+            nch = int(r["n_children"][k])
+            if r["total"][k] > 0:
+                pi[r["action"][k][:nch]] = r["visits"][k][:nch] / float(r["total"][k])
+            assert np.array_equal(pi, o["pi"][k]), (gidx, k)
+    ev.close()
