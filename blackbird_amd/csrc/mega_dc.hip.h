@@ -42,14 +42,33 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d, DCEdges E,
     double *tl = (double *)lds_all[wv];
     float *nl = (float *)lds_all[wv];
     if (lane == 0) myslot[wv] = g;
+#ifdef BB_STAMPS
+    double *lds = tl; // DST's accumulator sits past the policy image, outside the network's activations
+    if (lane < 16) ((unsigned long long *)(lds + 4032))[lane] = 0;
+#endif
     __threadfence_block();
     for (int p = 0; p < plies; p++) {
-        if (d.game_lid[g] < 0) return; // this slot has played its last game
+        if (d.game_lid[g] < 0) break; // this slot has played its last game
         for (int s = 0; s < sims; s++) {
+#ifdef BB_STAMPS
+            long long c0 = clock64();
+#endif
             dc_fused_tree(d, E, g, lane, tl);
+#ifdef BB_STAMPS
+            long long c1 = clock64();
+#endif
             if (d.pend_leaf[g] >= 0) // (uniform) a leaf was posted: evaluate it right here
                 dc_fused_net(nd, d, &myslot[wv], nl, noise_on);
+#ifdef BB_STAMPS
+            DST(0, c1 - c0);          // tree phases (tools/dc_stamps.py)
+            DST(2, clock64() - c1);   // network
+            DST(4, 1);
+#endif
         }
         dc_fused_move(d, E, g, lane, tl);
     }
+#ifdef BB_STAMPS
+    if (lane == 0 && d.stamps)
+        for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[(size_t)(g & 63) * 16 + i], ((unsigned long long *)(lds + 4032))[i]);
+#endif
 }

@@ -16,3 +16,5 @@ n = st[4]
 print(f"per game-step cycles: apply {st[0]/n:.0f} (expansions {st[8]/n:.2f} per step: gather+noise {st[5]/max(st[8],1):.0f}, np_sum {st[6]/max(st[8],1):.0f}, edge write {st[7]/max(st[8],1):.0f}), select {st[2]/n:.0f}; move generation {st[9]/max(st[8],1):.0f}")
 print(f"select per game-step: levels {st[1]/n:.2f}; first loads {st[11]/n:.0f}, node rows {st[12]/n:.0f} ({st[12]/max(st[1],1):.0f} per level), edge rows {st[13]/n:.0f} ({st[13]/max(st[1],1):.0f} per level), PUCT + argmax {st[14]/n:.0f} ({st[14]/max(st[1],1):.0f} per level), child creation / leaf state / tail {st[15]/n:.0f}")
 print(f"apply: entry -> first round of loads complete {st[10]/n:.0f}, second round {st[3]/n:.0f}")
+if eng.selfplay_mode() == 5:
+    print(f"one wave per game (mega_dc.hip.h): in the first line 'apply' is then the tree phases of a simulation (apply + select) = {st[0]/n:.0f} cycles and 'select' the network evaluation = {st[2]/n:.0f} cycles")
