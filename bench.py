@@ -66,10 +66,10 @@ def cpu_baseline(flat, seconds_budget=20.0, sims=800):
 
 def pmc_traffic_bytes_per_second():
     """HBM bytes/s of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    collected in separate runs, profiles/r01_v5_queue_pmc_summary.json).  FETCH_SIZE is used as reported: the
+    collected in separate runs, profiles/r01_v6_queue_pmc_summary.json).  FETCH_SIZE is used as reported: the
     tree kernels read scattered 4-16 B fields, not the wide streams for which MI355X_MICROARCH.md gives the x2
     correction, so the read side is a lower bound."""
-    path = os.path.join(ROOT, "profiles", "r01_v5_queue_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r01_v6_queue_pmc_summary.json")
     try:
         with open(path) as f:
             p = json.load(f)
@@ -223,7 +223,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": (pmc_traffic_bytes_per_second() * net_ms * 1e-3) if (mode >= 2 and pmc_traffic_bytes_per_second()) else None,
-                         "traffic_note": "HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) rate from profiles/r01_v5_queue_pmc_summary.json x this launch's duration",
+                         "traffic_note": "HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) rate from profiles/r01_v6_queue_pmc_summary.json x this launch's duration",
                          "launch_ms_mean": net_ms, "launch_ms_min": net_min_ms,
                          "launches_timed": net_n, "flops_per_launch": flops_per_launch},
         }
