@@ -893,7 +893,10 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
                 }
                 break;
             }
-            if (mask == 0) { leaf_found = true; break; }
+            // (DynamicMCTS.py:29 also stops at an expanded node without legal actions.  On these boards a node is expanded
+            // only if it is not terminal, and a non-terminal board has an empty cell, so the case cannot arise; likewise a
+            // path cannot outgrow MAXPATH = H*W + 2 edges, one move each.  Two loop exits less in the hottest loop.)
+            static_assert(G::MAXPATH >= G::H * G::W + 2, "a descent places at most H*W stones");
 #if BB_PREFETCH_BEST
             { // the most visited child is the likeliest next step: pull its row towards this CU while the PUCT arithmetic runs
                 int key = (ci >= 0 && lane < A) ? ((Ni << 4) | lane) : -1;
@@ -909,7 +912,6 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
             double u = puct_score(child_q(d, Qi, 0.f, Ni), cPi, sq, Ni, lane < A && ((mask >> lane) & 1u));
             int child = ci;
             int a = grp_argmax<S>(u, lane, child);
-            if (depth >= G::MAXPATH) { overflow = 1; leaf_found = true; break; }
             if (lane == 0) path[depth] = ((uint32_t)cur << 6) | ((uint32_t)((flags >> 4) & 3) << 4) | (uint32_t)a;
             if (child == CHILD_NONE) {
                 typename G::State st2;
