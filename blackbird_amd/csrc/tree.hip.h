@@ -838,11 +838,14 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
         else cur = d.root[g];
         int nn = d.n_nodes[g];
         typename G::State st;
-        int flags = 0, expand = 0, overflow = 0;
-        bool have = false, parked = false, leaf_found = false, term = false;
+        int flags = 0;
+        // Outcome bits of the descent, one integer per lane on purpose: as separate bools they live in scalar lane masks and
+        // every exit of the loop below pays a three-instruction merge for each of them on every iteration
+        enum { F_HAVE = 1, F_PARKED = 2, F_LEAF = 4, F_TERM = 8, F_EXPAND = 16, F_OVERFLOW = 32 };
+        int fl = 0;
         int pf_touch = 0; // speculative touch of the likeliest child's row (BB_PREFETCH_BEST)
         for (;;) {
-            if (budget <= 0) { parked = true; break; }
+            if (budget <= 0) { fl |= F_PARKED; break; }
             budget--;
 #ifdef BB_STAMPS_DEEP
             long long ts0 = clock64();
@@ -862,15 +865,15 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
 #ifdef BB_STAMPS_DEEP
             st_load += clock64() - ts0;
 #endif
-            if (!have) {
+            if (!(fl & F_HAVE)) {
                 st = st_l;
                 flags = flags_l;
             }
-            have = false;
+            fl &= ~F_HAVE;
             if (!(flags & NODE_EXPANDED)) {
-                leaf_found = true;
+                fl |= F_LEAF;
                 if (flags & NODE_TERMINAL) {
-                    term = true;
+                    fl |= F_TERM;
                     if (flags & NODE_CACHED) { // value already known: finish this simulation here
 #ifdef BB_STAMPS_DEEP
                         long long sb0 = clock64();
@@ -886,10 +889,10 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
 #ifdef BB_STAMPS_DEEP
                         s_backup += clock64() - sb0;
 #endif
-                        leaf_found = false; // nothing to post; start the next simulation
+                        fl &= ~F_LEAF; // nothing to post; start the next simulation
                     }
                 } else {
-                    expand = 1;
+                    fl |= F_EXPAND;
                 }
                 break;
             }
@@ -917,24 +920,24 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
                 typename G::State st2;
                 bool terminal;
                 child = create_child<G>(d, g, pool, node, st, a, lane, nn, st2, terminal);
-                if (child == CHILD_NONE) { overflow = 1; leaf_found = true; break; }
+                if (child == CHILD_NONE) { fl |= F_OVERFLOW | F_LEAF; break; }
                 st = st2;
                 flags = (terminal ? NODE_TERMINAL : 0) | (gs_player(st2) << 4);
-                have = true;
+                fl |= F_HAVE;
             }
             depth++;
             cur = child & ~CHILD_TERM_BIT;
         }
         if (lane == 0) {
-            d.resume_cur[g] = parked ? cur : -1;
-            d.resume_depth[g] = parked ? depth : 0;
+            d.resume_cur[g] = (fl & F_PARKED) ? cur : -1;
+            d.resume_depth[g] = (fl & F_PARKED) ? depth : 0;
         }
-        if (parked) break;
-        if (!leaf_found) {           // cached terminal: loop on to the next simulation (or the move)
+        if (fl & F_PARKED) break;
+        if (!(fl & F_LEAF)) {           // cached terminal: loop on to the next simulation (or the move)
             if (lane == 0) d.sim_serial[g] += 1;
             continue;
         }
-        if (d.eval_noise && expand && lane < A) // Beta(alpha,1-alpha) prior noise for this expansion, one action per lane
+        if (d.eval_noise && (fl & F_EXPAND) && lane < A) // Beta(alpha,1-alpha) prior noise for this expansion, one action per lane
             d.eval_noise[(size_t)g * S + lane] =
                 bb_beta_noise(d.seed, d.first_game_id + (uint32_t)d.game_lid[g], (uint32_t)cur, (uint32_t)lane, d.noise_alpha);
         if (lane == 0) {             // post the leaf for the evaluator
@@ -942,15 +945,15 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
             d.leaf_game_id[g] = d.first_game_id + (uint32_t)d.game_lid[g];
             d.leaf_serial[g] = cur;
             d.pend_leaf[g] = cur;
-            d.pend_expand[g] = expand;
+            d.pend_expand[g] = (fl & F_EXPAND) ? 1 : 0;
             d.path_len[g] = depth;
             d.sim_serial[g] += 1;
             d.evals[g] += 1;
-            d.ctr[(size_t)g * 8 + 6] += (uint64_t)overflow;
+            d.ctr[(size_t)g * 8 + 6] += (uint64_t)((fl & F_OVERFLOW) ? 1 : 0);
         }
         sims_done++;
         depth_sum += depth;
-        term_hits += term ? 1 : 0;
+        term_hits += (fl & F_TERM) ? 1 : 0;
         posted = true;
         break;
     }
