@@ -182,6 +182,41 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
             if (live && sub == 0) nz[q] = r >= 0.0f ? r : nd.alpha;
         }
     }
+    if constexpr (PW == 1) {
+        // one position per wave (work-queue kernel, small batches): lane a finishes action a, so the softmax costs one
+        // expf and two divisions per wave instead of 7 and 14 on lane 0 (vector issue is what the persistent kernel is
+        // short of).  The oracle's ordered sums (tot += p[a], a ascending) run over v_readlane broadcasts: same values,
+        // same order, bit-identical to the sequential form below.
+        if (pos0 < n) {
+            const int D = nd.D, pos = OI(pos0);
+            const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
+            const bool act = lane < A;
+            const float l = act ? lg[lane] : -INFINITY;
+            auto lane_f = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+            float m = -INFINITY;
+#pragma unroll
+            for (int a = 0; a < A; a++) m = fmaxf(m, lane_f(l, a));
+            float pr = act ? expf(l - m) : 0.f;
+            float tot = 0.f;
+#pragma unroll
+            for (int a = 0; a < A; a++) tot += lane_f(pr, a);
+            pr = pr / tot;
+            if (noise) { // policy = (1-eps)*softmax + eps*Beta(alpha,1-alpha); policy /= sum(policy)
+                pr = (1.0f - nd.eps) * pr + nd.eps * (act ? nz[lane] : 0.f);
+                float t2 = 0.f;
+#pragma unroll
+                for (int a = 0; a < A; a++) t2 += lane_f(pr, a);
+                pr = pr / t2;
+            }
+            if (act && logits_out) logits_out[(size_t)pos * A + lane] = l;
+            if (act && policy_out) policy_out[(size_t)pos * pstride + lane] = pr;
+            if (lane == 0 && value_out) {
+                float e = d2b[0];
+                for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(sd[dd], d2k[dd], e);
+                value_out[pos] = tanhf(e);
+            }
+        }
+    } else
     if (lane < PW && pos0 + lane < n) { // one lane finishes each position (sequential, oracle order)
         const int D = nd.D, pp = lane, pos = OI(pos0 + lane);
         const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
