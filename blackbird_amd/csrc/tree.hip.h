@@ -841,7 +841,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
         int flags = 0;
         // Outcome bits of the descent, one integer per lane on purpose: as separate bools they live in scalar lane masks and
         // every exit of the loop below pays a three-instruction merge for each of them on every iteration
-        enum { F_HAVE = 1, F_PARKED = 2, F_LEAF = 4, F_TERM = 8, F_EXPAND = 16, F_OVERFLOW = 32 };
+        enum { F_PARKED = 2, F_LEAF = 4, F_TERM = 8, F_EXPAND = 16, F_OVERFLOW = 32 };
         int fl = 0;
         int pf_touch = 0; // speculative touch of the likeliest child's row (BB_PREFETCH_BEST)
         for (;;) {
@@ -865,11 +865,8 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
 #ifdef BB_STAMPS_DEEP
             st_load += clock64() - ts0;
 #endif
-            if (!(fl & F_HAVE)) {
-                st = st_l;
-                flags = flags_l;
-            }
-            fl &= ~F_HAVE;
+            st = st_l;
+            flags = flags_l;
             if (!(flags & NODE_EXPANDED)) {
                 fl |= F_LEAF;
                 if (flags & NODE_TERMINAL) {
@@ -921,9 +918,14 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
                 bool terminal;
                 child = create_child<G>(d, g, pool, node, st, a, lane, nn, st2, terminal);
                 if (child == CHILD_NONE) { fl |= F_OVERFLOW | F_LEAF; break; }
+                // the node just created is the leaf of this descent (never expanded, never cached): finish here instead of
+                // going round the loop once more to read back the row that was written a moment ago
                 st = st2;
                 flags = (terminal ? NODE_TERMINAL : 0) | (gs_player(st2) << 4);
-                fl |= F_HAVE;
+                depth++;
+                cur = child & ~CHILD_TERM_BIT;
+                fl |= F_LEAF | (terminal ? F_TERM : F_EXPAND);
+                break;
             }
             depth++;
             cur = child & ~CHILD_TERM_BIT;
