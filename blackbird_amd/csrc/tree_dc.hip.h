@@ -492,6 +492,13 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
             flags = (terminal ? NODE_TERMINAL : 0) | ((int)st2.player << 4);
             have = true;
             __threadfence_block();
+            if (!inline_expand && !fixed) { // the node just created is this descent's leaf: no need to go round once more to read it back
+                depth++;
+                cur = child & ~CHILD_TERM_BIT;
+                if (terminal) term_leaf = 1;
+                else expand = 1;
+                break;
+            }
         }
         depth++;
         cur = child & ~CHILD_TERM_BIT;
