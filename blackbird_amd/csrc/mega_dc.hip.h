@@ -29,7 +29,7 @@ __device__ __attribute__((noinline)) void dc_fused_move(const TreeDev &d, const 
     __threadfence_block();
 }
 
-__global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d, DCEdges E, NetDev nd, int plies, int sims, int noise_on) {
+__global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdges E_arg, NetDev nd_arg, int plies, int sims, int noise_on) {
     using NG = NetGeom<DragonChess, 1>;
     // the tree's scratch (the 4032-double policy image) and the network's activations are never live together
     constexpr int TREE_BYTES = DC_LDS_DOUBLES * 8, NET_BYTES = NG::WAVE_FLOATS * 4;
@@ -37,6 +37,20 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d, DCEdges E,
     static_assert(4 * WAVE_BYTES + 64 <= 163840, "four waves' scratch must fit the 160 KiB LDS");
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[4][WAVE_BYTES];
     __shared__ int myslot[4];
+    // the phase functions take the three descriptor structs by reference: from LDS copies (made once) rather than from a
+    // per-lane scratch copy of the kernel arguments -- a lone wave feels every round trip of its ~100 field loads per call
+    __shared__ TreeDev s_d;
+    __shared__ DCEdges s_E;
+    __shared__ NetDev s_nd;
+    if (threadIdx.x == 0) {
+        s_d = d_arg;
+        s_E = E_arg;
+        s_nd = nd_arg;
+    }
+    __syncthreads();
+    const TreeDev &d = s_d;
+    const DCEdges &E = s_E;
+    const NetDev &nd = s_nd;
     const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (g >= d.n_slots) return;
     double *tl = (double *)lds_all[wv];
