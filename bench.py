@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- self-play throughput of the MI355X engine on BASELINE.json's headline configuration.
 
-Workload (configs[1], "C2"): Connect4 7x6, 800 simulations/move, 4096 concurrent self-play games
-per GPU, network R4/F16/D16 random-init (weight seed 0), c_puct 0.85, temp 1, Beta prior noise
-alpha 0.2 / eps 0.3 (always on in the reference, NetworkFactory.py:176-180), float32.
+Workloads (--workload):
+  c2 (default, the headline; BASELINE configs[1]): Connect4 7x6, 800 simulations/move, 4096 concurrent self-play games
+     per GPU, network R4/F16/D16 random-init (weight seed 0), c_puct 0.85, temp 1, Beta prior noise alpha 0.2 / eps 0.3
+     (always on in the reference, NetworkFactory.py:176-180), float32.
+  c5 (configs[4] on one GPU): the same game with the 20-block x 256-filter network (one step is 3.3 M evaluations of
+     1.98 GFLOP: use --steps 1 --warmup 0 --prefill 1).
+  dc (configs[3]): DragonChess, 400 simulations/move, 1024 concurrent games, R4/F16/D16 on 17 planes, 4032-wide policy
+     head, ply cap 512 (the reference has no draw rule: documented deviation).
 
-A "step" is one ply of every concurrent game: 800 visits of every game by the persistent self-play kernel (or
-800 x (tree kernel + network kernel) + one move kernel in the launch-per-round modes).  Finished games hand their
-slot to a fresh game, so the batch stays full; `value` is games completed inside the timed region / wall time (whole
-job, all ranks).  The timed region = the K steps + the extraction to the host of the example records of as many
-finished games as it produced (SURVEY.md 8d counts example extraction in the metric).  Before warm-up the
-games are de-synchronised by an untimed prefill at 32 simulations/move (otherwise all 4096 games
-would start and finish in lock-step and a short timed window would see no completions).
+A "step" is `sims` tree visits of every concurrent game -- one launch-unit of the persistent self-play kernel (or `sims`
+x (tree kernel + network kernel) + one move kernel in the launch-per-round modes).  A visit completes at least one
+simulation (more when it meets terminal leaves whose value is already known), so a step is at least one ply of every
+game; `plies_per_step` says how many it was.  Finished games hand their slot to a fresh game, so the batch stays full;
+`value` is games completed inside the timed region / wall time (whole job, all ranks).  The timed region = the K steps +
+the extraction to the host of the example records of as many finished games as it produced (SURVEY.md 8d counts example
+extraction in the metric).  Before warm-up the games are de-synchronised by an untimed prefill at few simulations per
+move (otherwise all games would start and finish in lock-step and a short timed window would see no completions);
+`games_per_sec_steady` = plies/s / mean plies of the games that finished in the timed region is the renewal-rate
+estimate that does not depend on where the window falls.
 
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL), disjoint game-id/RNG
-streams per rank, no collective in the data path; the (s, pi, z) examples of the timed region are
-all-gathered once after timing (the epoch-end exchange of SURVEY.md 8e).  Under torch.distributed.run the ranks are
-what the launcher made them; `python bench.py --gpus N` without a launcher starts that same command itself.
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL), disjoint game-id/RNG streams per rank, no
+collective in the data path; the (s, pi, z) examples are all-gathered once after timing, device to device
+(blackbird_amd/dist.py; the epoch-end exchange of SURVEY.md 8e).  Under torch.distributed.run the ranks are what the
+launcher made them; `python bench.py --gpus N` without a launcher starts that same command itself.
 
-usage: python bench.py [--gpus N] [--steps K] [--warmup W]
+usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c5|dc]
 """
 import argparse
 import json
@@ -34,21 +42,70 @@ sys.path.insert(0, ROOT)
 
 from blackbird_amd import _lib, weights as W  # noqa: E402
 
-FLOPS_PER_EVAL = 1_588_700  # SURVEY.md 8d / BASELINE.md: C2 network, conv + heads
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+FLOPS_PER_EVAL_C2 = 1_588_700  # SURVEY.md 8d / BASELINE.md: C2 network, conv + heads
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec (6290 measured copy)
+
+WORKLOADS = {
+    # game, H*W, planes, actions, blocks, filters, sims, slots, max_plies, prefill (plies, sims/move), steps, warmup, BASELINE configs index
+    "c2": dict(game=_lib.GAME_CONNECT4, name="Connect4 7x6", hw=42, C=3, A=7, blocks=4, filters=16, sims=800, slots=4096,
+               max_plies=42, prefill=(64, 32), steps=32, warmup=8, cfg=1, min_game_plies=7),
+    "c5": dict(game=_lib.GAME_CONNECT4, name="Connect4 7x6", hw=42, C=3, A=7, blocks=20, filters=256, sims=800, slots=4096,
+               max_plies=42, prefill=(64, 32), steps=32, warmup=8, cfg=4, min_game_plies=7),
+    "dc": dict(game=_lib.GAME_DRAGONCHESS, name="DragonChess 8x8", hw=64, C=17, A=4032, blocks=4, filters=16, sims=400,
+               slots=1024, max_plies=512, prefill=(192, 8), steps=32, warmup=4, cfg=3, min_game_plies=3),
+}
 
 
-def cpu_baseline(flat, seconds_budget=20.0, sims=800):
-    """Oracle ("port" of the reference's serial algorithm) on the host cores: one independent
-    game per thread, same network/seed/noise as the GPU run.  Bounded: one game per thread."""
+def flops_per_eval(w):
+    """F_eval = 2 HW 9 C F + 4 R HW 9 F^2 + 6 HW F + 4 A + 4 D  (D = 16)."""
+    hw, C, F, R, A = w["hw"], w["C"], w["filters"], w["blocks"], w["A"]
+    return 2 * hw * 9 * C * F + 4 * R * hw * 9 * F * F + 6 * hw * F + 4 * A + 4 * 16
+
+
+def tree_bytes_per_sim(w, mean_depth, mean_children):
+    """SURVEY.md 8d B_sim: 16 A_c d (select reads) + 16 (d+1) (backup) + 16 A_c + 2 S (expand) + HW C (leaf planes) +
+    4 (A+1) (network outputs read back); A_c = child slots per stored node (7 dense for Connect4, the mean legal count
+    for DragonChess), S = state bytes (24 / 104 as the survey counts them)."""
+    S = 104 if w["game"] == _lib.GAME_DRAGONCHESS else 24
+    return 16 * mean_children * mean_depth + 16 * (mean_depth + 1) + 16 * mean_children + 2 * S + w["hw"] * w["C"] + 4 * (w["A"] + 1)
+
+
+def host_cpu():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return os.cpu_count() or 1, model
+
+
+def cpu_baseline(key, w, flat, gpu_mean_plies, budget_s=20.0):
+    """The oracle (a compiled "port" of the reference's serial algorithm: one game, one simulation, one batch-1 forward at
+    a time, float32) on EVERY host core, one independent game per thread, same network / noise as the GPU run.
+    Bounded to about `budget_s` seconds: c2 plays one full game per thread; for dc and c5 a full game would take minutes
+    to hours, so every thread plays the first plies of a game and games/s is extrapolated from the measured plies/s
+    (simulations/s for c5) with the mean game length the GPU run observed."""
     from oracle import orc
-    ow = orc.NetWeights(6, 7, 3, 16, 4, 16, 7, flat)
-    cfg = orc.make_cfg(orc.C4, evaluator=orc.EVAL_NET, net=ow, noise_on=True, alpha=0.2, eps=0.3, seed=1234)
-    cores = min(os.cpu_count() or 1, 16)
+    og = {"c2": orc.C4, "c5": orc.C4, "dc": orc.DC}[key]
+    H, Wd = (8, 8) if key == "dc" else (6, 7)
+    ow = orc.NetWeights(H, Wd, w["C"], w["filters"], w["blocks"], 16, w["A"], flat)
+    cfg = orc.make_cfg(og, evaluator=orc.EVAL_NET, net=ow, noise_on=True, alpha=0.2, eps=0.3, seed=1234)
+    cores, model = host_cpu()
+    if key == "c2":
+        sims, plies_cap, what = w["sims"], 42, "full Connect4 games at 800 sims/move"
+    elif key == "dc":
+        sims, plies_cap, what = w["sims"], 2, "the first 2 plies of a DragonChess game at 400 sims/move"
+    else:
+        sims, plies_cap, what = 4, 1, "one Connect4 ply of 4 simulations with the 20x256 network (~2 GFLOP per evaluation)"
     res = [None] * cores
 
     def work(i):
-        res[i] = orc.selfplay_game(cfg, 10_000_000 + i, 1.0, sims, 42)
+        res[i] = orc.selfplay_game(cfg, 10_000_000 + i, 1.0, sims, plies_cap)
 
     t0 = time.time()
     th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
@@ -58,39 +115,60 @@ def cpu_baseline(flat, seconds_budget=20.0, sims=800):
         t.join()
     dt = time.time() - t0
     tot_sims = sum(r["stats"].sims for r in res)
-    return {"value": cores / dt, "unit": "games/s", "cores": cores, "kind": "port",
-            "sims_per_s": tot_sims / dt,
-            "sample": f"{cores} full Connect4 games at {sims} sims/move, one per host thread, "
-                      f"{sum(r['n'] - 1 for r in res)} plies, {dt:.1f} s wall"}
+    plies = sum(r["n"] - 1 for r in res)
+    out = {"unit": "games/s", "cores": cores, "nproc": cores, "cpu_model": model, "kind": "port",
+           "port_note": "oracle/ C restatement of the reference's serial search; ONE network evaluation per simulation "
+                        "(value + priors of the expanded node together) where the reference runs 1 + b batch-1 sess.run "
+                        "calls per simulation (SURVEY.md 3.2), so this baseline is faster than the reference itself",
+           "sims_per_s": tot_sims / dt, "plies_per_s": plies / dt, "wall_s": dt}
+    if key == "c2":
+        out["value"] = cores / dt
+        out["sample"] = f"{cores} {what}, one per host thread, {plies} plies, {dt:.1f} s wall"
+    else:
+        per_game = max(gpu_mean_plies, 1.0)
+        rate = (plies / dt) if key == "dc" else (tot_sims / dt / w["sims"])   # plies per second
+        out["value"] = rate / per_game
+        out["sample"] = (f"{cores} threads x {what} ({plies} plies, {tot_sims} simulations, {dt:.1f} s wall); games/s "
+                         f"extrapolated = plies/s / {per_game:.1f} plies per game (the GPU run's mean finished-game length"
+                         + ("; plies/s = simulations/s / 800)" if key == "c5" else ")"))
+    return out
 
 
-def pmc_traffic_bytes_per_second():
-    """HBM bytes/s of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    collected in separate runs, profiles/r01_v6_queue_pmc_summary.json).  FETCH_SIZE is used as reported: the
-    tree kernels read scattered 4-16 B fields, not the wide streams for which MI355X_MICROARCH.md gives the x2
-    correction, so the read side is a lower bound."""
-    path = os.path.join(ROOT, "profiles", "r01_v6_queue_pmc_summary.json")
-    try:
-        with open(path) as f:
-            p = json.load(f)
-        return (p["hbm_read_GBps_raw"] + p["hbm_write_GBps"]) * 1e9
-    except (OSError, KeyError, ValueError):
-        return None
+def pmc_traffic_bytes_per_second(key):
+    """HBM bytes/s of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate runs; profiles/README.md).  FETCH_SIZE is used as reported: the tree side reads scattered 4-32 B fields, not
+    the wide streams for which MI355X_MICROARCH.md gives the x2 correction, so the read side is a lower bound."""
+    for name in {"c2": ("r02_queue_pmc_summary.json", "r01_v6_queue_pmc_summary.json"),
+                 "dc": ("r02_dc_pmc_summary.json",), "c5": ()}[key]:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                p = json.load(f)
+            return (p["hbm_read_GBps_raw"] + p["hbm_write_GBps"]) * 1e9, name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--slots", type=int, default=4096)
-    ap.add_argument("--sims", type=int, default=800)
-    ap.add_argument("--prefill", type=int, default=64, help="untimed de-synchronisation plies at 32 sims/move")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--slots", type=int, default=None)
+    ap.add_argument("--sims", type=int, default=None)
+    ap.add_argument("--prefill", type=int, default=None, help="untimed de-synchronisation plies at few sims/move")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
-                    help="c2 = BASELINE configs[1] (default, the headline); c5 = the same game with the 20-block x "
-                         "256-filter network of configs[4] (one ply is 3.3 M evaluations: use --steps 1 --warmup 0 --prefill 1)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
+                    help="c2 = BASELINE configs[1] (default, the headline); c5 = configs[4]'s 20x256 network on one GPU "
+                         "(use --steps 1 --warmup 0 --prefill 1); dc = configs[3] DragonChess 1024 games x 400 sims")
     args = ap.parse_args()
+    w = dict(WORKLOADS[args.workload])
+    K = w["steps"] if args.steps is None else args.steps
+    Wm = w["warmup"] if args.warmup is None else args.warmup
+    slots = w["slots"] if args.slots is None else args.slots
+    sims = w["sims"] if args.sims is None else args.sims
+    prefill = w["prefill"][0] if args.prefill is None else args.prefill
+    w["sims"] = sims
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # started by hand for several GPUs: become the launcher (a child process, before anything touches a GPU) --
@@ -108,6 +186,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = None
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -122,32 +201,32 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    game = _lib.GAME_CONNECT4
-    K, Wm = args.steps, args.warmup
-    blocks, filters = (20, 256) if args.workload == "c5" else (4, 16)
-    flat = W.flatten(W.init_weights(3, filters, blocks, 16, 7, seed=0))
-    # F_eval = 2 HW 9 C F + 4 R HW 9 F^2 + 6 HW F + 4 A + 4 D
-    flops_per_eval = 2 * 42 * 9 * 3 * filters + 4 * blocks * 42 * 9 * filters * filters + 6 * 42 * filters + 4 * 7 + 4 * 16
-    assert args.workload != "c2" or flops_per_eval == FLOPS_PER_EVAL
-    total_plies = args.prefill + Wm + K + 2
-    # every slot finishes at most one game per 7 plies (shortest Connect4 game)
-    max_games = args.slots * (total_plies // 7 + 2)
+    game = w["game"]
+    flat = W.flatten(W.init_weights(w["C"], w["filters"], w["blocks"], 16, w["A"], seed=0))
+    fpe = flops_per_eval(w)
+    assert args.workload != "c2" or fpe == FLOPS_PER_EVAL_C2
+    total_plies = prefill + Wm + K + 2
+    # every slot finishes at most one game per `min_game_plies` plies (a visit can complete several simulations, so a
+    # step can be more than one ply: x2 head-room)
+    max_games = slots * (2 * total_plies // w["min_game_plies"] + 2)
+    if args.workload == "dc":
+        max_games = slots * 3  # DragonChess games last tens to hundreds of plies
     from blackbird_amd import dist as bdist
     first_id, seed = bdist.shard(rank, 1234)
-    eng = _lib.Engine(game, n_slots=args.slots, sims_per_move=args.sims, evaluator=_lib.EVAL_NET, c_puct=0.85,
+    eng = _lib.Engine(game, n_slots=slots, sims_per_move=sims, evaluator=_lib.EVAL_NET, c_puct=0.85,
                       seed=seed, first_game_id=first_id, noise_on=True, alpha=0.2, epsilon=0.3,
-                      device=local, max_games=max_games)
+                      device=local, max_games=max_games, max_plies=w["max_plies"])
     eng.load_weights(flat)
     eng.selfplay_begin(max_games, 1.0)
-    if args.prefill > 0:
-        eng.set_sims_per_move(32)
-        eng.selfplay_step(args.prefill)
-        eng.set_sims_per_move(args.sims)
+    if prefill > 0:
+        eng.set_sims_per_move(min(w["prefill"][1], sims))
+        eng.selfplay_step(prefill)
+        eng.set_sims_per_move(sims)
     if Wm > 0:
         eng.selfplay_step(Wm)
     eng.synchronize()
     eng.reset_counters()
-    eng.timing_enable(97)  # HIP events around every 97th network launch of the timed region
+    eng.timing_enable(97)  # HIP events (engine stream) around every persistent launch / every 97th network launch
 
     def barrier():
         if dist is not None:
@@ -168,75 +247,114 @@ def main():
     dt = time.perf_counter() - t0
 
     net_ms, net_min_ms, net_n = eng.timing_read()
-    games, sims, plies = cnt["games_finished"], cnt["sims"], cnt["plies"]
-    tot = np.array([games, sims, plies, dt], dtype=np.float64)
+    games, nsims, plies = cnt["games_finished"], cnt["sims"], cnt["plies"]
+    # game lengths of what finished inside the timed region (game ids are dealt in order, so "finished" is not a prefix:
+    # read every header once)
+    rec_all, offs_all, win_all = eng.fetch_examples(0, max_games)
+    lens = np.diff(offs_all)
+    fin = np.nonzero(lens > 0)[0]
+    # records of games that were finished when the timed region began carry nothing new: the timed region's games are
+    # those whose LAST record's total-visit count belongs to a full-strength search or that finished after the snapshot;
+    # the length statistic simply uses every finished game of the run that started at full strength
+    first_tot = rec_all["total"][offs_all[fin]] if len(fin) else np.zeros(0)
+    full = fin[first_tot >= sims - 1] if len(fin) else fin
+    mean_plies_all = float((lens[fin] - 1).mean()) if len(fin) else 0.0
+    mean_plies_full = float((lens[full] - 1).mean()) if len(full) else 0.0
     if dist is not None:
+        dev = f"cuda:{local}" if backend == "nccl" else None
+        (games, nsims, plies), (dt,) = bdist.reduce_totals([games, nsims, plies], [dt], device=dev)
+        # epoch-end exchange: all-gather the finished games' (s, pi, z) records
         import torch
-        t = torch.tensor(tot, device="cuda")
-        tmax = t.clone()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        games, sims, plies = [float(x) for x in t[:3].tolist()]
-        dt = float(tmax[3])
-        # epoch-end exchange: all-gather the finished games' (s, pi, z) records over RCCL
-        from blackbird_amd import dist as bdist
-        rec, offs, win = eng.fetch_examples(0, max_games)
         tg = time.perf_counter()
-        allrec = bdist.allgather_records(rec, device=f"cuda:{local}")
-        torch.cuda.synchronize()
+        if backend == "nccl":   # device-resident: engine store -> compaction on the GPU -> RCCL -> GPU
+            allrec, _counts = bdist.allgather_engine_examples(eng, f"cuda:{local}")
+            torch.cuda.synchronize()
+            n_examples_all = int(allrec.shape[0])
+        else:
+            n_examples_all = int(len(bdist.allgather_records(rec_all)))
         allgather_s = time.perf_counter() - tg
-        n_examples_all = int(len(allrec))
     else:
         allgather_s = None
         n_examples_all = None
 
+    rc = 0
     if rank == 0:
         mode = eng.selfplay_mode()
-        if mode >= 2:
-            # persistent kernel: a launch covers up to 16 plies; its FLOPs are the evaluations it performed
-            kernel = {2: "k_selfplay_mega<Connect4> (4 network + 4 tree waves per CU, lock-step phases)",
-                      3: "k_selfplay_queue<Connect4,8> (8 network + 4 tree waves per CU, LDS work queue)",
-                      4: "k_selfplay_team<Connect4,2> (2 teams of 3 network waves + 6 tree waves per CU)"}[mode]
-            launches = max(net_n, 1)
-            flops_per_launch = flops_per_eval * cnt["evals"] / launches
+        gname = {"c2": "Connect4", "c5": "Connect4", "dc": "DragonChess"}[args.workload]
+        if mode == 3:
+            kernel = f"k_selfplay_queue<{gname},8> (8 network + 4 tree waves per CU, LDS work queue)"
+        elif mode == 5:
+            kernel = "k_dc_selfplay_fused (one wave per game: tree step, network and move in the same wave)"
+        elif w["filters"] != 16:
+            kernel = "k_gnet_conv<%s,false,4,2> x %d conv layers + first conv + heads per evaluation batch" % (gname, 2 * w["blocks"])
         else:
-            kernel = "k_net_compact<Connect4,4>" if mode == 1 else "k_net_fused16<Connect4,4>"
-            if filters != 16:
-                kernel = "k_gnet_conv<Connect4,false,4,2> x %d conv layers + first conv + heads per evaluation batch" % (2 * blocks)
-            flops_per_launch = flops_per_eval * cnt["evals"] / (K * args.sims)
+            kernel = f"k_net_compact<{gname},4>" if mode == 1 else f"k_net_fused16<{gname}>"
+        if mode >= 2:
+            # persistent kernel: a launch covers up to 16 steps; its FLOPs are the evaluations it performed
+            launches = max(net_n, 1)
+            flops_per_launch = fpe * cnt["evals"] / launches
+            sims_per_launch = cnt["sims"] / launches
+        else:
+            flops_per_launch = fpe * cnt["evals"] / max(K * sims, 1)
+            sims_per_launch = cnt["sims"] / max(K * sims, 1)
         achieved = flops_per_launch / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
+        mean_depth = cnt["sum_depth"] / max(cnt["sims"], 1)
+        a_c = 7.0 if gname == "Connect4" else 14.6   # DragonChess: mean legal count of SURVEY.md 6 [probe]
+        b_sim = tree_bytes_per_sim(w, mean_depth, a_c)
+        tree_gbps = b_sim * sims_per_launch / (net_ms * 1e-3) / 1e9 if net_ms > 0 else 0.0
+        traffic_rate, traffic_src = pmc_traffic_bytes_per_second(args.workload)
+        mean_len = mean_plies_full or mean_plies_all
         out = {
             "metric": "selfplay_games_per_sec", "value": games / dt, "unit": "games/s",
-            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3,
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / max(K, 1) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (self-play from the initial position, random-init weights seed 0)",
-            "config": {"workload": "Connect4 7x6, DynamicMCTS 800 sims/move, %d concurrent games per GPU, "
-                                   "net R%d/F%d/D16 fp32, noise alpha 0.2 eps 0.3 (BASELINE configs[%d])"
-                                   % (args.slots, blocks, filters, 4 if args.workload == "c5" else 1),
-                       "game": "Connect4", "sims_per_move": args.sims, "concurrent_games_per_gpu": args.slots,
-                       "blocks": blocks, "filters": filters, "step": "800 tree+network rounds over all games (one ply in lock-step terms)",
-                       "launch_structure": ["lockstep", "async-rounds", "persistent-phases", "persistent-queue", "persistent-teams", "wave-per-game"][mode],
+            "config": {"workload": "%s, DynamicMCTS %d sims/move, %d concurrent games per GPU, net R%d/F%d/D16 fp32, "
+                                   "noise alpha 0.2 eps 0.3 (BASELINE configs[%d])"
+                                   % (w["name"], sims, slots, w["blocks"], w["filters"], w["cfg"]),
+                       "game": gname, "sims_per_move": sims, "concurrent_games_per_gpu": slots,
+                       "blocks": w["blocks"], "filters": w["filters"], "max_plies": w["max_plies"],
+                       "step": "%d tree visits of every game (>= one ply each; see plies_per_step)" % sims,
+                       "launch_structure": ["lockstep", "async-rounds", "retired", "persistent-queue", "retired", "wave-per-game"][mode],
+                       "prefill": "%d plies at %d sims/move (untimed)" % (prefill, min(w["prefill"][1], sims)),
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
-            "node_evals_per_sec": sims / dt, "net_evals_per_sec_rank0": cnt["evals"] / dt, "plies_per_sec": plies / dt,
-            "games_finished": games, "examples_fetched": int(len(rec_t)), "examples_fetch_s": fetch_s, "terminal_leaf_fraction": cnt["terminal_leaves"] / max(cnt["sims"], 1),
-            "mean_leaf_depth": cnt["sum_depth"] / max(cnt["sims"], 1), "overflow": cnt["overflow"],
+            "node_evals_per_sec": nsims / dt, "net_evals_per_sec_rank0": cnt["evals"] / dt, "plies_per_sec": plies / dt,
+            "plies_per_step": plies / max(K, 1) / (slots * world),
+            "games_finished": games, "mean_plies_finished_games": mean_plies_all,
+            "mean_plies_games_started_at_full_sims": mean_plies_full,
+            "games_per_sec_steady": (plies / dt) / mean_len if mean_len > 0 else None,
+            "examples_fetched": int(len(rec_t)), "examples_fetch_s": fetch_s,
+            "terminal_leaf_fraction": cnt["terminal_leaves"] / max(cnt["sims"], 1),
+            "mean_leaf_depth": mean_depth, "overflow": cnt["overflow"],
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": (pmc_traffic_bytes_per_second() * net_ms * 1e-3) if (mode >= 2 and pmc_traffic_bytes_per_second()) else None,
-                         "traffic_note": "HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) rate from profiles/r01_v6_queue_pmc_summary.json x this launch's duration",
+                         "traffic": (traffic_rate * net_ms * 1e-3) if (mode >= 2 and traffic_rate) else None,
+                         "traffic_note": ("HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) rate from profiles/%s x this "
+                                          "launch's duration" % traffic_src) if traffic_src else "no PMC pass committed for this workload",
                          "launch_ms_mean": net_ms, "launch_ms_min": net_min_ms,
-                         "launches_timed": net_n, "flops_per_launch": flops_per_launch},
+                         "launches_timed": net_n, "flops_per_launch": flops_per_launch, "flops_per_eval": fpe,
+                         "tree_side": {"bound": "hbm", "bytes_per_sim": b_sim, "achieved": tree_gbps, "peak": PEAK_HBM_GBPS,
+                                       "unit": "GB/s", "frac": tree_gbps / PEAK_HBM_GBPS,
+                                       "note": "SURVEY.md 8d B_sim x simulations of the launch / launch time: latency-bound "
+                                               "pointer chasing, reported for completeness"}},
         }
         if allgather_s is not None:
             out["examples_allgather_s"] = allgather_s
             out["examples_gathered"] = n_examples_all
-        if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
-            out["cpu_baseline"] = cpu_baseline(flat)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["examples_allgather_path"] = "device (engine store -> RCCL)" if backend == "nccl" else "host (gloo rehearsal)"
+        if cnt["overflow"]:
+            # a pool ran out or a persistent launch aborted: the games are not the specified workload any more
+            out["value"] = None
+            out["error"] = "overflow counter is %d: result invalid" % cnt["overflow"]
+            rc = 1
+        elif world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, w, flat, mean_len)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
         print(json.dumps(out))
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

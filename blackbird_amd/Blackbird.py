@@ -5,7 +5,6 @@ game, examples in ply order plus the terminal example, Blackbird.py:219-268) but
 concurrently on the GPU: every tree, every leaf evaluation and every move runs in the HIP engine
 (bb_selfplay_*); the host only turns finished example records into protobuf blobs.
 """
-import random
 from collections import defaultdict
 
 import numpy as np
@@ -73,12 +72,17 @@ def GenerateTrainingSamples(model, nGames, temp):
     if nGames <= 0:
         raise ValueError('Use a positive integer for number of games.')
     game_cls = model.Game
-    eng = model._selfplay_engine(min(nGames, MAX_CONCURRENT_GAMES), nGames)
+    eng = model._selfplay_engine(nGames)
+    # every call is a fresh draw, as in the reference (new numpy choices and new graph noise each time): a new Philox
+    # key from numpy's generator (advancing it) and game ids that continue where the model's last run stopped
+    eng.set_rng_stream(int(np.random.randint(0, 2 ** 62, dtype=np.int64)), model._games_played)
+    model._games_played = (model._games_played + nGames) % (1 << 31)
+    eng.reset_counters()
     eng.selfplay_begin(nGames, temp)
     while not eng.selfplay_done()[0]:
         eng.selfplay_step(4)
-    if eng.counters()['overflow']:
-        raise _lib.BlackbirdHipError('search tree outgrew the node pool')
+        if eng.counters()['overflow']:  # pool exhausted, a parked slot or an aborted launch: the games would never finish
+            raise _lib.BlackbirdHipError('self-play stopped: a search tree outgrew its node pool or a launch was aborted')
     rec, offs, _win = eng.fetch_examples(0, nGames)
     # (s, pi, z) of every example in bulk: AsInputArray planes by one bb_game_encode call per chunk, pi = visits / total in
     # float64 exactly as Node.ChildProbability forms it, wire blobs assembled as one byte matrix -- then one PutGames per
@@ -136,46 +140,32 @@ def TrainWithExamples(model, batchSize, learningRate, epochs=1, teacher=None, mo
     model.Conn.PutModel(model.Game.GameType, model.Name, model.Version)
 
 
-def TestModels(model1, model2, temp, numTests):
-    """Blackbird.py:177-216: returns 1 / 0 / -1 for model1's win / draw / loss."""
-    for _ in range(numTests):
-        model1ToMove = random.choice([True, False])
-        model1Player = 1 if model1ToMove else 2
-        winner = None
-        model1.DropRoot()
-        model2.DropRoot()
-        state = model1.Game()
-        while winner is None:
-            if model1ToMove:
-                (nextState, *_) = model1.FindMove(state, temp)
-            else:
-                (nextState, *_) = model2.FindMove(state, temp)
-            state = nextState
-            model1.MoveRoot(state)
-            model2.MoveRoot(state)
-            model1ToMove = not model1ToMove
-            winner = state.Winner()
-        if winner == model1Player:
-            return 1
-        elif winner == 0:
-            return 0
-        else:
-            return -1
-
-
 def TestModelsBatched(model1, model2, temp, numTests, **kw):
     """All `numTests` games of TestModels at once on the GPU (blackbird_amd/arena.py); returns an array of +1/0/-1."""
     from .arena import TestModelsBatched as run
     return run(model1, model2, temp, numTests, **kw)
 
 
+def TestModels(model1, model2, temp, numTests):
+    """Blackbird.py:177-216: one head-to-head game, +1 / 0 / -1 for model1's win / draw / loss.  (The reference's
+    loop over numTests returns at the end of its first game, so one game is what a call plays.)  The game itself --
+    coin toss for the first move, FindMove on the mover's turns, MoveRoot for both after every move -- runs in the
+    batched arena with a batch of one."""
+    if numTests <= 0:
+        return None
+    return int(TestModelsBatched(model1, model2, temp, 1)[0])
+
+
 def _tally(model, opponent, temp, numTests, opName, opVersion=0):
-    resultMap = {1: 'wins', 0: 'draws', -1: 'losses'}
+    """The Test* wrappers (Blackbird.py:84-174): numTests games, every result logged, counts returned.  All games are
+    played concurrently by the batched arena; results are logged in game order."""
     stats = defaultdict(int)
-    for _ in range(numTests):
-        result = TestModels(model, opponent, temp, numTests=1)
-        stats[resultMap.get(result, 'indeterminant')] += 1
-        model.Conn.PutTrainingStatistic(result, model.Name, model.Version, opName, opVersion)
+    if numTests <= 0:
+        return stats
+    names = {1: 'wins', 0: 'draws', -1: 'losses'}
+    for result in TestModelsBatched(model, opponent, temp, numTests):
+        stats[names.get(int(result), 'indeterminant')] += 1
+        model.Conn.PutTrainingStatistic(int(result), model.Name, model.Version, opName, opVersion)
     return stats
 
 
@@ -198,30 +188,27 @@ def TestGood(model, temp, numTests):
 
 
 class Model(MCTS, Network):
-    """Blackbird.py:315-389: tree search powered by the network; both halves live in the HIP engine."""
+    """Blackbird.py:315-389: a searcher whose evaluator is its own network; both halves live in the HIP engine."""
     _EVALUATOR = _lib.EVAL_NET
 
     def __init__(self, game, name, mctsConfig, networkConfig={}, tensorflowConfig={}):
+        self.Game, self.Name = game, name
+        self.MCTSConfig, self.NetworkConfig, self.TensorflowConfig = mctsConfig, networkConfig, tensorflowConfig
         self.Conn = Connection()
-        self.Game = game
-        self.Name = name
-        self.Version = self.Conn.GetLastVersion(self.Game.GameType, self.Name)
-        self._saveName = self.Name + '_' + str(self.Version)
-        self.MCTSConfig = mctsConfig
-        self.NetworkConfig = networkConfig
-        self.TensorflowConfig = tensorflowConfig
-        MCTS.__init__(self, **mctsConfig)
+        self.Version = self.Conn.GetLastVersion(game.GameType, name)
+        self._saveName = '%s_%s' % (name, self.Version)
         self._batch_engine = None
-        gi = _lib.game_info(game.GAME_ID)
+        self._games_played = 0  # self-play games this model has started: the next run's first global game id
+        MCTS.__init__(self, **mctsConfig)
+        factory = None
         if networkConfig != {}:
-            Network.__init__(self, self._saveName,
-                             NetworkFactory(networkConfig, game.LegalMoves, inputShape=(gi.H, gi.W, gi.C)),
-                             tensorflowConfig)
-        else:
-            Network.__init__(self, self._saveName, tensorflowConfig=tensorflowConfig)
+            gi = _lib.game_info(game.GAME_ID)
+            factory = NetworkFactory(networkConfig, game.LegalMoves, inputShape=(gi.H, gi.W, gi.C))
+        Network.__init__(self, self._saveName, factory, tensorflowConfig)
 
     def LastVersion(self):
-        return Model(self.Game, self.Name, self.MCTSConfig, self.NetworkConfig, self.TensorflowConfig)
+        """Blackbird.py:347-348: a second Model built from the same arguments (it loads the last saved version)."""
+        return type(self)(self.Game, self.Name, self.MCTSConfig, self.NetworkConfig, self.TensorflowConfig)
 
     # ---- engine plumbing -----------------------------------------------------------------------------------
     def _make_engine(self, game_id, n_slots, sims, **kw):
@@ -243,41 +230,49 @@ class Model(MCTS, Network):
         self.SampleValue.cache_clear()
         self.GetPriors.cache_clear()
 
-    def _selfplay_engine(self, n_slots, n_games):
+    def _selfplay_engine(self, n_games):
+        """The batch engine for a GenerateTrainingSamples run: as many concurrent game slots as the run has games, capped
+        at MAX_CONCURRENT_GAMES and at what the device's free memory holds (DragonChess pools are sized for 512 plies x
+        PlayLimit nodes with 24 edges each: ~0.16 GB per slot at 400 simulations); further games queue on the slots."""
         if self.PlayLimit is None:
-            raise ValueError('Not enough information to decide a stop time.')
+            raise ValueError('Not enough information to decide a stop time.')  # (a wall-clock limit has no batched meaning)
+        want = min(n_games, MAX_CONCURRENT_GAMES)
         eng = self._batch_engine
-        if eng is None or eng.n_slots != n_slots or eng.cfg.max_games < n_games:
-            if eng is not None:
-                eng.close()
+        if eng is not None and (eng.cfg.max_games < n_games or getattr(eng, '_want', 0) < want or eng.cfg.sims_per_move != int(self.PlayLimit)):
+            eng.close()
+            eng = self._batch_engine = None
+        if eng is None:
+            n_slots, _per_slot = _lib.fit_slots(self.Game.GAME_ID, want, int(self.PlayLimit), max_games=n_games)
             eng = self._make_engine(self.Game.GAME_ID, n_slots, self.PlayLimit, max_games=n_games)
             eng.load_weights(W.flatten(self._ensure_weights(eng.info.C)))
+            eng._want = want
             self._batch_engine = eng
         return eng
 
-    # ---- Model overrides (Blackbird.py:350-389), kept for callers that use them directly ---------------------
-    class _Cached(object):
+    # ---- the Model overrides of the reference (Blackbird.py:350-389), for callers that use them directly; the search
+    # itself evaluates leaves inside the engine.  `cache_clear` exists because TrainWithExamples calls it (:288-289);
+    # nothing is memoised on the host.
+    class _Uncached(object):
         def __init__(self, fn):
             self._fn = fn
 
         def __get__(self, obj, objtype=None):
-            import functools
-            bound = functools.partial(self._fn, obj)
-            bound.cache_clear = lambda: None  # evaluations are not memoised on the host
+            def bound(*args):
+                return self._fn(obj, *args)
+            bound.cache_clear = lambda: None
             return bound
 
-    def _sample_value(self, state, player):
-        value = self.getEvaluation(state.AsInputArray())
-        value = (value + 1) * 0.5
-        if state.Player != player:
-            value = 1 - value
-        assert value >= 0, 'Value: {}'.format(value)
-        return value
+    def _value_for(self, state, player):
+        """SampleValue: the network's tanh value of `state` mapped to [0, 1], from `player`'s side."""
+        mine = (self.getEvaluation(state.AsInputArray()) + 1) * 0.5   # float32 arithmetic, as under numpy >= 2
+        out = mine if state.Player == player else 1 - mine
+        assert out >= 0, 'Value: {}'.format(out)
+        return out
 
-    def _get_priors(self, state):
-        policy = self.getPolicy(state.AsInputArray()) * state.LegalActions()
-        policy /= np.sum(policy)
-        return policy
+    def _priors_for(self, state):
+        """GetPriors: the network policy restricted to the legal moves, renormalised."""
+        masked = state.LegalActions() * self.getPolicy(state.AsInputArray())
+        return masked / np.sum(masked)
 
-    SampleValue = _Cached(_sample_value)
-    GetPriors = _Cached(_get_priors)
+    SampleValue = _Uncached(_value_for)
+    GetPriors = _Uncached(_priors_for)

@@ -74,6 +74,10 @@ class Network:
     def train(self, state, eval, policy, learningRate=0.01, teacher=None):
         """Network.py:66-84 (see blackbird_amd/training.py for the loss)."""
         from .training import Trainer
+        if teacher is not None:
+            # the reference's teacher branch (NetworkFactory.py:205-218) calls the removed tf.log and cannot run; refusing
+            # is better than silently training without the term
+            raise NotImplementedError('policy distillation from a teacher (hasTeacher) is not supported')
         state = np.asarray(state)
         self._ensure_weights(state.shape[-1])
         if self._trainer is None:
@@ -100,5 +104,6 @@ class Network:
         if not os.path.isfile(path):
             return False
         self._weights = W.load_npz(path)
+        self._trainer = None  # parameters and optimiser state of the old weights do not carry over
         self._weights_changed()
         return True

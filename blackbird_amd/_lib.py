@@ -22,7 +22,7 @@ EXPORTS = (
     "bb_game_encode", "bb_game_initial", "bb_create", "bb_destroy", "bb_load_weights", "bb_get_counters",
     "bb_reset_counters", "bb_synchronize", "bb_set_sims_per_move", "bb_timing_enable", "bb_timing_read", "bb_timing_net", "bb_selfplay_mode", "bb_net_eval", "bb_hash_eval", "bb_set_roots", "bb_run_sims", "bb_run_sims_masked",
     "bb_sample_moves", "bb_move_roots", "bb_get_root_states", "bb_selfplay_begin", "bb_selfplay_step",
-    "bb_selfplay_done", "bb_examples_fetch", "bb_examples_device",
+    "bb_selfplay_done", "bb_examples_fetch", "bb_examples_device", "bb_net_eval_keyed", "bb_set_rng_stream", "bb_fit_slots",
 )
 
 
@@ -90,6 +90,9 @@ def lib():
     L.bb_timing_net.argtypes = [vp, ip, ip, ip, C.POINTER(C.c_double)]
     L.bb_selfplay_mode.argtypes = [vp]
     L.bb_net_eval.argtypes = [vp, ip, vp, vp, vp, vp, vp, ip]
+    L.bb_net_eval_keyed.argtypes = [vp, ip, vp, vp, vp, vp, vp, vp, vp]
+    L.bb_set_rng_stream.argtypes = [vp, C.c_uint64, C.c_uint32]
+    L.bb_fit_slots.argtypes = [C.POINTER(Config), C.POINTER(ip), C.POINTER(C.c_uint64)]
     L.bb_hash_eval.argtypes = [vp, ip, vp, vp, vp]
     L.bb_set_roots.argtypes = [vp, ip, vp, vp, vp]
     L.bb_run_sims.argtypes = [vp, ip]
@@ -101,7 +104,7 @@ def lib():
     L.bb_selfplay_step.argtypes = [vp, ip]
     L.bb_selfplay_done.argtypes = [vp, C.POINTER(ip), C.POINTER(ip)]
     L.bb_examples_fetch.argtypes = [vp, ip, ip, vp, ip, vp, vp]
-    L.bb_examples_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.bb_examples_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(vp)]
     for name in EXPORTS:
         if name != "bb_last_error":
             getattr(L, name).restype = C.c_int
@@ -255,6 +258,19 @@ def example_dtype(game):
     return dt
 
 
+def fit_slots(game, n_slots, sims_per_move, *, mcts_kind=MCTS_DYNAMIC, max_depth=10, max_plies=None, max_games=None,
+              node_capacity=0, device=0):
+    """bb_fit_slots: (largest slot count <= n_slots whose pools fit the device's free memory, bytes per slot)."""
+    if max_plies is None:
+        max_plies = {GAME_CONNECT4: 42, GAME_TICTACTOE: 9}.get(game, 512)
+    cfg = Config(game=game, n_slots=n_slots, mcts_kind=mcts_kind, max_depth=max_depth, evaluator=EVAL_NET,
+                 sims_per_move=sims_per_move, max_plies=max_plies, max_games=max_games or n_slots, c_puct=1.0,
+                 device=device, node_capacity=node_capacity)
+    fit, per = C.c_int(), C.c_uint64()
+    check(lib().bb_fit_slots(C.byref(cfg), C.byref(fit), C.byref(per)))
+    return fit.value, per.value
+
+
 # ---- engine ----------------------------------------------------------------------------------------------
 class Engine:
     """One GPU-resident batch of search trees (bb_engine)."""
@@ -271,9 +287,9 @@ class Engine:
                      seed=seed, hash_salt=hash_salt, first_game_id=first_game_id, noise_on=int(noise_on), alpha=alpha,
                      epsilon=epsilon, device=device, salt_per_game=int(salt_per_game), node_capacity=node_capacity)
         self.cfg = cfg
+        self.h = C.c_void_p()
         self.n_slots = n_slots
         self.max_plies = max_plies
-        self.h = C.c_void_p()
         check(lib().bb_create(C.byref(cfg), C.byref(self.h)))
         self._weights_keep = None
 
@@ -342,6 +358,30 @@ class Engine:
         check(lib().bb_net_eval(self.h, n, ptr(states), ptr(planes), ptr(value), ptr(logits), ptr(policy), int(noise)))
         return value, logits, policy
 
+    def net_eval_keyed(self, game_ids, node_serials, states=None, planes=None):
+        """bb_net_eval_keyed: the forward pass with the prior noise of (global game id, node serial) per position --
+        exactly the priors a self-play kernel uses for that node."""
+        A = self.info.A
+        if states is not None:
+            states = np.ascontiguousarray(states)
+            n = states.shape[0]
+        else:
+            planes = np.ascontiguousarray(planes, dtype=np.int8)
+            n = planes.shape[0]
+        gids = np.ascontiguousarray(game_ids, dtype=np.uint32).reshape(n)
+        sers = np.ascontiguousarray(node_serials, dtype=np.int32).reshape(n)
+        value = np.zeros(n, dtype=np.float32)
+        logits = np.zeros((n, A), dtype=np.float32)
+        policy = np.zeros((n, A), dtype=np.float32)
+        check(lib().bb_net_eval_keyed(self.h, n, ptr(states), ptr(planes), ptr(gids), ptr(sers), ptr(value), ptr(logits),
+                                      ptr(policy)))
+        return value, logits, policy
+
+    def set_rng_stream(self, seed, first_game_id=0):
+        check(lib().bb_set_rng_stream(self.h, C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint32(int(first_game_id) & 0xFFFFFFFF)))
+        self.cfg.seed = int(seed) & (2 ** 64 - 1)
+        self.cfg.first_game_id = int(first_game_id) & 0xFFFFFFFF
+
     def hash_eval(self, states):
         states = np.ascontiguousarray(states)
         n = states.shape[0]
@@ -407,3 +447,10 @@ class Engine:
         win = np.zeros(n_games, dtype=np.int8)
         k = check(lib().bb_examples_fetch(self.h, first_game, n_games, ptr(rec), cap, ptr(offs), ptr(win)))
         return rec[:k], offs, win
+
+    def examples_device(self):
+        """bb_examples_device: (records device pointer, bytes, record bytes, game header device pointer)."""
+        p, hdr = C.c_void_p(), C.c_void_p()
+        nb, rb = C.c_uint64(), C.c_uint64()
+        check(lib().bb_examples_device(self.h, C.byref(p), C.byref(nb), C.byref(rb), C.byref(hdr)))
+        return p.value, nb.value, rb.value, hdr.value

@@ -10,6 +10,7 @@ Per game the sequence (FindMove on my turns, MoveRoot after every move) is the r
 run is only the order in which random numbers are consumed across games, so results are identical for deterministic
 settings (temp = 0, no prior noise) and identically distributed otherwise (tests/test_gpu_arena.py)."""
 import random
+from time import time
 
 import numpy as np
 
@@ -20,16 +21,33 @@ from .RandomMCTS import RandomMCTS
 class _Searcher(object):
     """One side of the arena: an MCTS / FixedMCTS / Model object turned into an engine with one slot per game."""
 
-    def __init__(self, player, game_id, n_games, sims):
+    def __init__(self, player, game_id, n_games, sims, seconds):
         self.player = player
         self.random = isinstance(player, RandomMCTS)
         self.engine = None
+        self.sims = None if sims is None else int(sims)   # simulations per move (playLimit), or
+        self.seconds = seconds                             # wall-clock budget per move (timeLimit) when sims is None
         if not self.random:
             plies = {_lib.GAME_CONNECT4: 43, _lib.GAME_TICTACTOE: 10}.get(game_id, 64)
-            cap = min(player._MAX_NODES, int(sims) * plies * player._max_depth() + 64)
-            self.engine = player._make_engine(game_id, n_games, sims, node_capacity=cap)
+            cap = player._MAX_NODES
+            if self.sims is not None:
+                cap = min(cap, self.sims * plies * player._max_depth() + 64)
+            self.engine = player._make_engine(game_id, n_games, self.sims or 64, node_capacity=cap)
             player._after_engine_created(self.engine)  # a Model loads its weights here
             self.primed = np.zeros(n_games, dtype=bool)
+
+    def search(self, mask):
+        """_runMCTS (MCTS.py:284-303) on the slots of `mask`: playLimit simulations, or simulations in chunks until the
+        move's wall-clock budget is spent (at least one chunk, so the root is always expanded)."""
+        if self.sims is not None:
+            self.engine.run_sims(self.sims, mask=mask)
+            return
+        end = time() + self.seconds
+        while True:
+            self.engine.run_sims(16, mask=mask)
+            self.engine.synchronize()
+            if time() >= end:
+                break
 
     def close(self):
         if self.engine is not None:
@@ -41,8 +59,8 @@ def TestModelsBatched(model1, model2, temp, numTests, playLimit=None, first=None
     """Play `numTests` games of model1 against model2 concurrently; returns an int array of +1 / 0 / -1 (model1's
     wins / draws / losses), one entry per game, in game order.
 
-    playLimit  simulations per move for both sides (default: each side's own PlayLimit; the reference's time limits
-               have no batched meaning)
+    playLimit  simulations per move for both sides (default: each side's own PlayLimit; a side that only has a
+               TimeLimit searches all its games together until that many seconds have passed, every move)
     first      optional bool array: model1 moves first in game i (default: `random.choice([True, False])` per game,
                drawn in game order like the reference does at the top of each game)
     uniforms   optional callable n -> float64[n] supplying np.random.choice's uniforms (default np.random.random_sample)"""
@@ -57,9 +75,12 @@ def TestModelsBatched(model1, model2, temp, numTests, playLimit=None, first=None
     draw = uniforms if uniforms is not None else np.random.random_sample
     sides = []
     for m in (model1, model2):
-        sims = playLimit if playLimit is not None else (m.PlayLimit if getattr(m, 'PlayLimit', None) else 64)
-        sides.append(_Searcher(m, game_id, numTests, sims))
-        sides[-1].sims = int(sims)
+        # FindMove's stop rule (MCTS.py:173-182): playLimit simulations and / or timeLimit seconds per move
+        sims = playLimit if playLimit is not None else getattr(m, 'PlayLimit', None)
+        seconds = getattr(m, 'TimeLimit', None)
+        if sims is None and seconds is None and not isinstance(m, RandomMCTS):
+            raise ValueError('Not enough information to decide a stop time.')
+        sides.append(_Searcher(m, game_id, numTests, sims, seconds))
     try:
         states = np.repeat(_lib.game_initial(game_id), numTests, axis=0)   # packed boards, host side
         alive = np.ones(numTests, dtype=bool)
@@ -83,7 +104,9 @@ def TestModelsBatched(model1, model2, temp, numTests, playLimit=None, first=None
                 if len(fresh):
                     eng.set_roots(states[fresh], slots=fresh, game_ids=fresh)
                     side.primed[fresh] = True
-                eng.run_sims(side.sims, mask=mine)
+                side.search(mine)
+                if eng.counters()['overflow']:
+                    raise _lib.BlackbirdHipError('search tree outgrew the node pool')
                 u = np.zeros(numTests, dtype=np.float64)
                 if temp != 0:
                     u[idx] = draw(len(idx))

@@ -8,9 +8,7 @@
 #include "gnet.hip.h"
 #include "tree.hip.h"
 #include "tree_dc.hip.h"
-#include "mega.hip.h"
 #include "mega2.hip.h"
-#include "mega3.hip.h"
 #include "mega_dc.hip.h"
 
 #include <cmath>
@@ -209,8 +207,7 @@ struct bb_engine {
     TreeDev view[2];
     hipStream_t vstream[2] = {nullptr, nullptr};
     int vround[2] = {0, 0};
-    bool mega = false; // persistent per-CU self-play kernel (mega.hip.h)
-    int mega_queue = 0; // 1 work-queue kernel (mega2.hip.h), 2 work queue + network teams (mega3.hip.h)
+    bool mega = false; // persistent per-CU self-play kernel with an LDS work queue (mega2.hip.h)
     bool async_selfplay = false; // dense games, DynamicMCTS, deterministic evaluators: k_tree_async rounds
     bool dc_fused = false;       // DragonChess, DynamicMCTS, 16-filter network: one wave keeps its game for a whole launch (mega_dc.hip.h)
     int round = 0;
@@ -317,8 +314,32 @@ static void make_views(bb_engine *e) {
     }
 }
 
-extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
-    if (!cfg || !out) return fail(BB_ERR_ARG, "null argument");
+// ---- pool sizing ------------------------------------------------------------------------------------------------
+static long node_capacity_of(const bb_config *cfg) {
+    long cap = cfg->node_capacity > 0 ? cfg->node_capacity : (long)cfg->sims_per_move * cfg->max_plies + 2;
+    if (cfg->mcts_kind == BB_MCTS_FIXED && cfg->node_capacity <= 0) cap = cap * cfg->max_depth;
+    return cap;
+}
+
+// device bytes engine_alloc<G> asks for: per slot (node pool, DragonChess edge pool, mailboxes, paths) and per engine
+// (example store of max_games games)
+template <class G>
+static void pool_bytes(const bb_config *cfg, size_t *per_slot, size_t *fixed) {
+    constexpr bool DC = G::GID == BB_GAME_DRAGONCHESS;
+    constexpr size_t NODE_BYTES = DC ? sizeof(DCNode) : sizeof(DenseNode<typename std::conditional<DC, Connect4, G>::type>);
+    const size_t cap = (size_t)node_capacity_of(cfg);
+    size_t ps = cap * NODE_BYTES;
+    if (DC) ps += cap * 24 * sizeof(DCEdge) + (size_t)G::MAXPATH * 4;
+    ps += (size_t)G::MAXPATH * 4 + (DC ? (size_t)G::A : (size_t)G::S) * 4 + (size_t)G::S * 16 + sizeof(typename G::State) + 256;
+    bb_game_info gi;
+    bb_game_info_get(cfg->game, &gi);
+    const size_t ng = (size_t)(cfg->max_games > 0 ? cfg->max_games : cfg->n_slots);
+    *per_slot = ps;
+    *fixed = ng * ((size_t)(cfg->max_plies + 1) * (size_t)gi.example_bytes + 16) + (64u << 20); // + weights, scratch, runtime slack
+}
+
+static int check_config(const bb_config *cfg) {
+    if (!cfg) return fail(BB_ERR_ARG, "null argument");
     if (cfg->n_slots <= 0) return fail(BB_ERR_ARG, "n_slots must be positive");
     if (cfg->mcts_kind == BB_MCTS_FIXED && cfg->max_depth <= 0)
         return fail(BB_ERR_ARG, "MaxDepth for MCTS must be > 0."); // FixedMCTS.py:15-16
@@ -326,6 +347,42 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     int ndev = bb_device_count();
     if (ndev <= 0) return fail(BB_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(BB_ERR_ARG, "device %d out of range", cfg->device);
+    if (node_capacity_of(cfg) >= (1 << 26)) return fail(BB_ERR_ARG, "node capacity too large");
+    return BB_OK;
+}
+
+extern "C" int bb_fit_slots(const bb_config *cfg, int *n_slots_out, uint64_t *bytes_per_slot_out) {
+    int rc = check_config(cfg);
+    if (rc) return rc;
+    size_t per_slot = 0, fixed = 0;
+    GAME_SWITCH(cfg->game, pool_bytes<G>(cfg, &per_slot, &fixed); break);
+    HIPCHK(hipSetDevice(cfg->device));
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const size_t usable = free_b - free_b / 16; // leave 1/16 of what is free to the runtime and to other engines' scratch
+    long fit = usable > fixed ? (long)((usable - fixed) / per_slot) : 0;
+    if (fit > cfg->n_slots) fit = cfg->n_slots;
+    if (n_slots_out) *n_slots_out = (int)fit;
+    if (bytes_per_slot_out) *bytes_per_slot_out = (uint64_t)per_slot;
+    if (fit <= 0)
+        return fail(BB_ERR_CAPACITY, "not even one game slot (%zu bytes) + the example store (%zu bytes) fits the %zu free bytes of device %d",
+                    per_slot, fixed, free_b, cfg->device);
+    return BB_OK;
+}
+
+extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
+    if (!cfg || !out) return fail(BB_ERR_ARG, "null argument");
+    {
+        int rc = check_config(cfg);
+        if (rc) return rc;
+        int fit = 0;
+        uint64_t per_slot = 0;
+        rc = bb_fit_slots(cfg, &fit, &per_slot);
+        if (rc) return rc;
+        if (fit < cfg->n_slots)
+            return fail(BB_ERR_CAPACITY, "%d game slots of %llu bytes each do not fit the free memory of device %d (%d would; "
+                        "fewer slots play the same games one after another)", cfg->n_slots, (unsigned long long)per_slot, cfg->device, fit);
+    }
     bb_engine *e = new bb_engine();
     e->cfg = *cfg;
     e->sims_now = cfg->sims_per_move;
@@ -352,10 +409,7 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     d.seed = cfg->seed;
     d.salt = cfg->hash_salt;
     d.first_game_id = cfg->first_game_id;
-    long cap = cfg->node_capacity > 0 ? cfg->node_capacity : (long)cfg->sims_per_move * cfg->max_plies + 2;
-    if (cfg->mcts_kind == BB_MCTS_FIXED && cfg->node_capacity <= 0) cap = cap * cfg->max_depth;
-    if (cap >= (1 << 26)) return fail(BB_ERR_ARG, "node capacity too large");
-    d.node_cap = (int)cap;
+    d.node_cap = (int)node_capacity_of(cfg);
     d.example_bytes = e->info.example_bytes;
     d.gpw = 64 / e->info.S;
     d.level_budget = 16; // measured optimum 14-20 on MI355X, Connect4 @800 sims (profiles/README.md)
@@ -372,10 +426,8 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     if (const char *env = getenv("BB_ASYNC")) e->async_selfplay = e->async_selfplay && atoi(env) != 0;
     e->mega = e->async_selfplay && cfg->evaluator == BB_EVAL_NET;
     if (const char *env = getenv("BB_MEGA")) e->mega = e->mega && atoi(env) != 0;
-    e->mega_queue = e->mega ? 1 : 0; // default persistent kernel: the work-queue variant
     e->dc_fused = cfg->game == BB_GAME_DRAGONCHESS && cfg->mcts_kind == BB_MCTS_DYNAMIC && cfg->evaluator == BB_EVAL_NET;
     if (const char *env = getenv("BB_MEGA")) e->dc_fused = e->dc_fused && atoi(env) != 0;
-    if (const char *env = getenv("BB_MEGA_QUEUE")) e->mega_queue = e->mega ? atoi(env) : 0; // 1 work queue, 2 work queue + network teams
     if (const char *env = getenv("BB_TREE_GPW")) {
         int v = atoi(env);
         if (v >= 1 && v <= 64 / e->info.S) d.gpw = v;
@@ -450,7 +502,7 @@ extern "C" int bb_selfplay_mode(bb_engine *e) {
     if (!e) return fail(BB_ERR_ARG, "null engine");
     // the persistent kernels carry a 16-filter network of at most MEGA_RMAX blocks in LDS; anything else runs as rounds
     const bool fits = !e->has_weights || (!e->general_net && e->net.R <= MEGA_RMAX && e->net.head_floats <= MEGA_HEAD_FLOATS);
-    if (e->mega && fits) return e->mega_queue == 2 ? 4 : (e->mega_queue == 1 ? 3 : 2);
+    if (e->mega && fits) return 3;
     if (e->dc_fused && (!e->has_weights || !e->general_net)) return 5;
     return e->async_selfplay ? 1 : 0;
 }
@@ -714,17 +766,20 @@ static int launch_net(bb_engine *e, int n, const typename G::State *states, cons
 
 template <class G>
 static int net_eval(bb_engine *e, int n, const void *states, const int8_t *planes, float *value, float *logits,
-                    float *policy, int noise) {
+                    float *policy, int noise, const uint32_t *game_ids = nullptr, const int32_t *serials = nullptr) {
     const int A = G::A;
     size_t pb = (size_t)n * G::H * G::W * G::C;
-    DevBuf din, dv, dl, dp;
+    DevBuf din, dv, dl, dp, dg, dser;
     if (din.alloc(states ? (size_t)n * sizeof(typename G::State) : pb) || dv.alloc((size_t)n * 4) ||
-        dl.alloc((size_t)n * A * 4) || dp.alloc((size_t)n * A * 4))
+        dl.alloc((size_t)n * A * 4) || dp.alloc((size_t)n * A * 4) || dg.alloc((size_t)n * 4) || dser.alloc((size_t)n * 4))
         return BB_ERR_HIP;
     HIPCHK(hipMemcpy(din.p, states ? states : (const void *)planes, states ? (size_t)n * sizeof(typename G::State) : pb,
                      hipMemcpyDefault));
+    if (game_ids) HIPCHK(hipMemcpy(dg.p, game_ids, (size_t)n * 4, hipMemcpyDefault));
+    if (serials) HIPCHK(hipMemcpy(dser.p, serials, (size_t)n * 4, hipMemcpyDefault));
     int rc = launch_net<G>(e, n, states ? (const typename G::State *)din.p : nullptr,
-                           states ? nullptr : (const int8_t *)din.p, nullptr, nullptr, noise, (float *)dv.p,
+                           states ? nullptr : (const int8_t *)din.p, game_ids ? (const uint32_t *)dg.p : nullptr,
+                           serials ? (const int32_t *)dser.p : nullptr, noise, (float *)dv.p,
                            (float *)dl.p, (float *)dp.p, A, e->stream);
     if (rc) return rc;
     HIPCHK(sync_all(e));
@@ -741,6 +796,16 @@ extern "C" int bb_net_eval(bb_engine *e, int n, const void *states, const int8_t
     if (!e->has_weights) return fail(BB_ERR_WEIGHTS, "bb_load_weights has not been called");
     HIPCHK(hipSetDevice(e->cfg.device));
     GAME_SWITCH(e->cfg.game, return net_eval<G>(e, n, states, planes, value_out, logits_out, policy_out, noise));
+}
+
+extern "C" int bb_net_eval_keyed(bb_engine *e, int n, const void *states, const int8_t *planes, const uint32_t *game_ids,
+                                 const int32_t *node_serials, float *value_out, float *logits_out, float *policy_out) {
+    if (e && n == 0) return BB_OK;
+    if (!e || n < 0 || (!states == !planes) || !game_ids || !node_serials)
+        return fail(BB_ERR_ARG, "bad arguments (exactly one of states/planes; game_ids and node_serials are required)");
+    if (!e->has_weights) return fail(BB_ERR_WEIGHTS, "bb_load_weights has not been called");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    GAME_SWITCH(e->cfg.game, return net_eval<G>(e, n, states, planes, value_out, logits_out, policy_out, 1, game_ids, node_serials));
 }
 
 template <class G>
@@ -802,8 +867,9 @@ static int launch_eval_inner(bb_engine *e) {
                                                            d.eval_value, d.eval_policy, G::S);
         break;
     case BB_EVAL_NET:
-        return launch_net<G>(e, n, ls, nullptr, d.leaf_game_id, d.leaf_serial, e->cfg.noise_on, d.eval_value, nullptr,
-                             d.eval_policy, (G::GID == BB_GAME_DRAGONCHESS) ? G::A : G::S, e->stream);
+        // (a wide game's prior noise is mixed in at expansion, over the legal moves only: tree_dc.hip.h)
+        return launch_net<G>(e, n, ls, nullptr, d.leaf_game_id, d.leaf_serial, (G::GID == BB_GAME_DRAGONCHESS) ? 0 : e->cfg.noise_on,
+                             d.eval_value, nullptr, d.eval_policy, (G::GID == BB_GAME_DRAGONCHESS) ? G::A : G::S, e->stream);
     case BB_EVAL_ROLLOUT:
         if constexpr (G::GID == BB_GAME_DRAGONCHESS)
             k_dc_rollout<<<nblk((size_t)n * 64), 256, 0, e->stream>>>(n, ls, d.leaf_game_id, d.sim_serial, d.pend_leaf, d.seed,
@@ -989,6 +1055,22 @@ extern "C" int bb_set_sims_per_move(bb_engine *e, int sims) {
     });
 }
 
+extern "C" int bb_set_rng_stream(bb_engine *e, uint64_t seed, uint32_t first_game_id) {
+    if (!e) return fail(BB_ERR_ARG, "null engine");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(sync_all(e));
+    e->cfg.seed = seed;
+    e->cfg.first_game_id = first_game_id;
+    e->dev.seed = seed;
+    e->dev.first_game_id = first_game_id;
+    for (int v = 0; v < 2; v++) {
+        e->view[v].seed = seed;
+        e->view[v].first_game_id = first_game_id;
+    }
+    e->net.seed = seed;
+    return BB_OK;
+}
+
 // ---- self-play ----------------------------------------------------------------------------------------
 extern "C" int bb_selfplay_begin(bb_engine *e, int n_games, double temp) {
     if (!e) return fail(BB_ERR_ARG, "null engine");
@@ -1044,29 +1126,8 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
             if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
             TreeDev dm = d;
             dm.eval_noise = (e->cfg.noise_on && getenv("BB_TREE_NOISE")) ? e->d_eval_noise : nullptr; // default: network waves draw the noise
-            if (e->mega_queue == 2) {
-                int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
-                if constexpr (G::S == 8) {
-                    if (getenv("BB_TEAM_WAVES") && atoi(getenv("BB_TEAM_WAVES")) == 2) // four teams of two waves, two positions per pass
-                        k_selfplay_team<G, 4, 2, 2><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
-                    else
-                        k_selfplay_team<G, 2><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
-                } else
-                    k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
-            } else if (e->mega_queue) {
-                int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
-                int netw = getenv("BB_QUEUE_NETW") ? atoi(getenv("BB_QUEUE_NETW")) : 8;
-                if constexpr (G::S == 8) {
-                    if (netw == 6) k_selfplay_queue<G, 6><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
-                    else if (netw == 7) k_selfplay_queue<G, 7><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
-                    else if (netw == 5) k_selfplay_queue<G, 5><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
-                    else k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
-                } else {
-                    k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
-                }
-            }
-            else
-                k_selfplay_mega<G><<<nb, MEGA_THREADS, 0, e->stream>>>(dm, e->net, 2 * rounds, e->cfg.noise_on);
+            const int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
+            k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
             HIPCHK(hipGetLastError());
             if (timed) {
                 HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
@@ -1228,11 +1289,13 @@ extern "C" int bb_examples_fetch(bb_engine *e, int first_game, int n_games, void
     return total;
 }
 
-extern "C" int bb_examples_device(bb_engine *e, void **ptr_out, uint64_t *bytes_out, uint64_t *record_bytes_out) {
+extern "C" int bb_examples_device(bb_engine *e, void **ptr_out, uint64_t *bytes_out, uint64_t *record_bytes_out,
+                                  int32_t **game_hdr_out) {
     if (!e) return fail(BB_ERR_ARG, "null engine");
     if (ptr_out) *ptr_out = e->dev.examples;
     if (bytes_out) *bytes_out = (uint64_t)e->cfg.max_games * (uint64_t)(e->cfg.max_plies + 1) * (uint64_t)e->info.example_bytes;
     if (record_bytes_out) *record_bytes_out = (uint64_t)e->info.example_bytes;
+    if (game_hdr_out) *game_hdr_out = e->dev.game_hdr;
     return BB_OK;
 }
 

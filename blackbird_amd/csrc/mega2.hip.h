@@ -1,8 +1,9 @@
-// mega2.hip.h -- persistent self-play kernel with a per-CU work queue instead of lock-step phases.
+// mega2.hip.h -- persistent self-play kernel: tree search and network evaluation of the SAME 16 games share one
+// workgroup (one CU) and hand leaves / evaluations to each other through that CU's LDS alone.
 //
-// k_selfplay_mega (mega.hip.h) alternates two sets of 8 games behind one workgroup barrier per phase, so every
-// phase lasts as long as its slowest wave and two network waves on a SIMD run their MFMA and their VALU
-// sections at the same time.  Here the 16 games of a workgroup circulate freely between
+// With one launch per phase (k_tree_async, k_net_compact) every round waits for the deepest descent among all 4096
+// games and the MFMA units idle while the latency-bound tree kernel runs.  Here the 16 games of a workgroup circulate
+// freely between
 //     4 tree waves   (4 games each, S lanes per game): apply result -> [move] -> descend -> post leaf
 //     8 network waves (2 per SIMD, one position each): pop leaf -> tower + heads -> publish result
 // through an LDS ring of game indices and a per-game state word.  A network wave's head/softmax VALU work
@@ -13,7 +14,11 @@
 // so it is placement-independent.  Every wait loop is bounded by wall-clock time: a protocol bug ends the
 // launch with the abort word set (reported through the overflow counter) instead of hanging the GPU.
 #pragma once
-#include "mega.hip.h"
+#include "net.hip.h"
+#include "tree.hip.h"
+
+#define MEGA_RMAX 4          // residual blocks whose weights fit the 160 KiB LDS next to the activations
+#define MEGA_HEAD_FLOATS 256 // packed head parameters that fit next to them
 
 #define MEGA2_THREADS 768 // 12 waves: NETW network waves + (12 - NETW) tree waves
 #define MEGA2_QCAP 32
@@ -291,7 +296,12 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
 #endif
     }
     __syncthreads();
-    if (threadIdx.x == 0 && qc.abort_flag) d.ctr[(size_t)g0 * 8 + 6] += 1; // surfaces as bb_counters.overflow
+    if (qc.abort_flag) { // a wait ran into the wall-clock limit: surfaces as bb_counters.overflow
+        if (threadIdx.x == 0) d.ctr[(size_t)g0 * 8 + 6] += 1;
+        // a leaf that was queued but never evaluated must not be applied by the next launch (its mailbox holds the
+        // previous evaluation): drop it, the simulation is redone from the root
+        if ((int)threadIdx.x < n_mine && gstate[threadIdx.x] == 1) shadow.pend_leaf[threadIdx.x] = -1;
+    }
     __syncthreads();
     shadow.store(dg, g0, n_mine, MEGA2_THREADS); // hand the per-game state back to HBM
 }

@@ -20,7 +20,8 @@ __device__ __attribute__((noinline)) void dc_fused_tree(const TreeDev &d, const 
     __threadfence_block();
 }
 __device__ __attribute__((noinline)) void dc_fused_net(const NetDev &nd, const TreeDev &d, const int *slot, float *nl, int noise_on) {
-    net_body<DragonChess, 1>(nd, 1, 0, slot, nl, (const DCState *)d.leaf_state, nullptr, d.leaf_game_id, d.leaf_serial, noise_on,
+    (void)noise_on; // the prior noise of a wide game is mixed in at expansion (dc_expand), over the legal moves only
+    net_body<DragonChess, 1>(nd, 1, 0, slot, nl, (const DCState *)d.leaf_state, nullptr, d.leaf_game_id, d.leaf_serial, 0,
                              d.eval_value, nullptr, d.eval_policy, DragonChess::A);
     __threadfence_block();
 }

@@ -153,7 +153,21 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
                     }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-                const float inv = 1.0f / tot;
+                float inv = 1.0f / tot;
+                if (noise) { // getPolicy through bb_net_eval: policy = (1-eps)*softmax + eps*Beta(alpha,1-alpha); policy /= sum(policy)
+                    // (the tree paths pass noise = 0 for wide games: they mix the draws in at expansion, tree_dc.hip.h)
+                    const uint32_t gid = game_id ? game_id[pos] : (uint32_t)noise, ser = serial ? (uint32_t)serial[pos] : (uint32_t)pos;
+                    float t2 = 0.f;
+#pragma unroll 1
+                    for (int k = 0; k < NPL; k++)
+                        if (lane + 64 * k < A) {
+                            sv[k] = (1.0f - nd.eps) * (sv[k] * inv) + nd.eps * bb_beta_noise(nd.seed, gid, ser, (uint32_t)(lane + 64 * k), nd.alpha);
+                            t2 += sv[k];
+                        }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) t2 += __shfl_xor(t2, o, 64);
+                    inv = 1.0f / t2;
+                }
 #pragma unroll
                 for (int k = 0; k < NPL; k++)
                     if (lane + 64 * k < A) outp[lane + 64 * k] = sv[k] * inv;
@@ -164,7 +178,7 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
                 value_out[pos] = tanhf(e);
             }
         }
-        return; // prior noise for wide games is mixed in at expansion (tree_dc.hip.h)
+        return;
     }
     if constexpr (A <= 64) {
     float *nz = lg + PW * A; // [PW][A] Beta(alpha, 1-alpha) draws, one lane per (position, action)

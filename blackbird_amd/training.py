@@ -8,7 +8,9 @@ Reproduced exactly as written in the reference graph, quirks included:
   * policy loss = -mean(log(policy) @ policyLabel^T)  -- the full BxB cross matrix      (:190-194)
   * L2 term     = mean over non-bias trainable variables of sum(v^2)/2, no coefficient  (:196-201)
   * batch norm runs in inference mode (moving statistics are constants), epsilon 1e-3
-  * optimiser: Adam / Momentum / plain SGD by config                                     (:234-242)
+  * optimiser: tf.compat.v1.train Adam / Momentum / GradientDescent by config, their update rules written out
+    in `Trainer._apply` (TF1's Adam puts epsilon outside the bias correction; torch.optim.Adam does not)  (:234-242)
+The teacher term (:205-218) calls the removed `tf.log` in the reference and cannot run there; Network.train refuses it.
 """
 import numpy as np
 import torch
@@ -29,16 +31,36 @@ class Trainer:
                 self.consts[k] = t
             else:
                 self.params[k] = t.requires_grad_(True)
-        self.kind, self.momentum = optimizer, momentum
-        self.opt = None
+        self.kind, self.momentum = optimizer, float(momentum)
+        # optimiser slots, one per trainable variable, as the TF1 optimisers keep them (NetworkFactory.py:234-242)
+        self.t = 0                                                         # AdamOptimizer's step count (beta powers)
+        self.m = {k: torch.zeros_like(v) for k, v in self.params.items()}  # Adam first moment / Momentum accumulator
+        self.v = {k: torch.zeros_like(v) for k, v in self.params.items()}  # Adam second moment
 
-    def _make_opt(self, lr):
-        ps = list(self.params.values())
-        if self.kind == 'adam':
-            return torch.optim.Adam(ps, lr=lr, betas=(0.9, 0.999), eps=1e-8)
-        if self.kind == 'momentum':
-            return torch.optim.SGD(ps, lr=lr, momentum=self.momentum)
-        return torch.optim.SGD(ps, lr=lr)
+    def _apply(self, grads, lr):
+        """One optimiser update, written out so that it is the reference's optimiser and not a look-alike:
+          tf.compat.v1.train.AdamOptimizer(lr) (beta1 0.9, beta2 0.999, epsilon 1e-8):
+              lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+              var -= lr_t * m / (sqrt(v) + epsilon)        (epsilon OUTSIDE the bias correction, unlike torch.optim.Adam)
+          MomentumOptimizer(lr, momentum): accum = momentum * accum + g;  var -= lr * accum
+          GradientDescentOptimizer(lr):    var -= lr * g"""
+        with torch.no_grad():
+            if self.kind == 'adam':
+                b1, b2, eps = 0.9, 0.999, 1e-8
+                self.t += 1
+                lr_t = lr * (1.0 - b2 ** self.t) ** 0.5 / (1.0 - b1 ** self.t)
+                for k, p in self.params.items():
+                    g = grads[k]
+                    self.m[k].mul_(b1).add_(g, alpha=1.0 - b1)
+                    self.v[k].mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                    p.sub_(lr_t * self.m[k] / (self.v[k].sqrt() + eps))
+            elif self.kind == 'momentum':
+                for k, p in self.params.items():
+                    self.m[k].mul_(self.momentum).add_(grads[k])
+                    p.sub_(lr * self.m[k])
+            else:
+                for k, p in self.params.items():
+                    p.sub_(lr * grads[k])
 
     def _get(self, k):
         return self.params[k] if k in self.params else self.consts[k]
@@ -78,19 +100,23 @@ class Trainer:
         lossParam = torch.stack(l2).mean()
         return lossEvaluation + lossPolicy + lossParam, (lossEvaluation, lossPolicy, lossParam)
 
-    def step(self, state, eval, policy, learningRate):
+    def gradients(self, state, eval, policy, noise=None):
+        """Loss, its three terms and d loss / d variable for one batch (what optimizer.minimize(loss) differentiates).
+        noise: the A Beta(alpha, 1-alpha) draws of the graph's Dirichlet node, or None to draw them."""
         boards = torch.tensor(np.asarray(state, dtype=np.float32), device=self.device)
         ev = torch.tensor(np.asarray(eval, dtype=np.float32).reshape(-1), device=self.device)
         pl = torch.tensor(np.asarray(policy, dtype=np.float32), device=self.device)
-        if self.opt is None:
-            self.opt = self._make_opt(float(learningRate))
-        for g in self.opt.param_groups:
-            g['lr'] = float(learningRate)
-        self.opt.zero_grad()
-        total, parts = self.loss(boards, ev, pl)
-        total.backward()
-        self.opt.step()
-        return float(total.detach()), [float(p.detach()) for p in parts]
+        if noise is not None:
+            noise = torch.tensor(np.asarray(noise, dtype=np.float32), device=self.device)
+        total, parts = self.loss(boards, ev, pl, noise)
+        names = list(self.params)
+        gs = torch.autograd.grad(total, [self.params[k] for k in names])
+        return float(total.detach()), [float(p.detach()) for p in parts], dict(zip(names, gs))
+
+    def step(self, state, eval, policy, learningRate, noise=None):
+        total, parts, grads = self.gradients(state, eval, policy, noise)
+        self._apply(grads, float(learningRate))
+        return total, parts
 
     def export(self):
         out = {k: v.detach().cpu().numpy().copy() for k, v in self.params.items()}

@@ -144,7 +144,14 @@ typedef struct {
     uint64_t evals;           /* leaves evaluated (< sims when known terminal values are reused) */
 } bb_counters;
 
+/* bb_create fails with BB_ERR_CAPACITY (before allocating anything) when the pools of cfg->n_slots games -- sized for the
+ * worst case: sims_per_move * max_plies nodes per game -- do not fit the device's free memory. */
 int bb_create(const bb_config *cfg, bb_engine **out);
+/* The largest slot count <= cfg->n_slots whose pools fit the free memory of cfg->device, and the bytes one slot takes.
+ * Games are independent and a slot plays game ids g, g+n_slots, ... one after another, so fewer slots change the
+ * schedule, never the results.  The reference has no such limit (one Python object graph per game, Blackbird.py:238-251);
+ * the batched GenerateTrainingSamples uses this to cap its concurrency.  BB_ERR_CAPACITY if not even one slot fits. */
+int bb_fit_slots(const bb_config *cfg, int *n_slots_out, uint64_t *bytes_per_slot_out);
 int bb_destroy(bb_engine *e);
 /* Network.__init__/loadModel (Network.py:10-28, 100-112): install weights for BB_EVAL_NET */
 int bb_load_weights(bb_engine *e, const bb_net_weights *w);
@@ -162,10 +169,10 @@ int bb_timing_read(bb_engine *e, double *mean_ms_out, double *min_ms_out, int *c
  * on the engine stream); ablate != 0 switches parts of the kernel off (kernel tuning only). */
 int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, double *ms_per_launch_out);
 /* Which launch structure bb_selfplay_step uses: 0 lock-step (one tree + one evaluator launch per
- * simulation), 1 asynchronous rounds, 2 persistent per-CU kernel in lock-step phases (tree + network waves in
- * one workgroup), 3 persistent per-CU kernel with a work queue between its tree and network waves (default for
- * networks that fit LDS), 4 work queue + teams of network waves per evaluation (experimental), 5 DragonChess with the
- * 16-filter network: one wave keeps its game for a whole launch -- tree step, network and move in the same wave. */
+ * simulation), 1 asynchronous rounds, 3 persistent per-CU kernel with a work queue between its tree and network
+ * waves (default for networks that fit LDS), 5 DragonChess with the 16-filter network: one wave keeps its game for a
+ * whole launch -- tree step, network and move in the same wave.  (2 and 4 were launch structures that measured slower
+ * and were retired: tools/experimental/.) */
 int bb_selfplay_mode(bb_engine *e);
 
 /* Network.getEvaluation + getPolicy for n positions (Network.py:48-64; graph NetworkFactory.py:22-183).
@@ -176,6 +183,12 @@ int bb_selfplay_mode(bb_engine *e);
  * Outputs may be NULL. */
 int bb_net_eval(bb_engine *e, int n, const void *states, const int8_t *planes, float *value_out,
                 float *logits_out, float *policy_out, int noise);
+/* The same forward pass with the prior-noise stream named explicitly: position i draws the Beta(alpha, 1-alpha) noise
+ * of (global game id game_ids[i], node serial node_serials[i]) -- the key the self-play kernels use for the node they
+ * expand -- so a checker can obtain exactly the priors the engine used inside a search
+ * (Model.GetPriors with the graph's noise, Blackbird.py:372-389 + NetworkFactory.py:176-182). */
+int bb_net_eval_keyed(bb_engine *e, int n, const void *states, const int8_t *planes, const uint32_t *game_ids,
+                      const int32_t *node_serials, float *value_out, float *logits_out, float *policy_out);
 /* the validation evaluator, same outputs (policy unnormalised, as getPolicy-shaped input to GetPriors) */
 int bb_hash_eval(bb_engine *e, int n, const void *states, float *value_out, float *policy_out);
 
@@ -202,6 +215,11 @@ int bb_sample_moves(bb_engine *e, double temp, const double *u, int32_t *action_
 int bb_move_roots(bb_engine *e, const int32_t *actions);
 int bb_get_root_states(bb_engine *e, void *states_out);
 
+/* Re-key the engine's random streams (Philox key `seed`; global id of local game 0).  The reference draws fresh numpy /
+ * TensorFlow randomness on every GenerateTrainingSamples call (MCTS.py:336-338, NetworkFactory.py:176-180); a caller
+ * that reuses an engine for another self-play run gives it a new stream here, otherwise the run repeats the last one. */
+int bb_set_rng_stream(bb_engine *e, uint64_t seed, uint32_t first_game_id);
+
 /* ---- batched self-play: Blackbird.GenerateTrainingSamples (Blackbird.py:219-268) ------------- */
 /* Start `n_games` games (local ids 0..n_games-1; slot g plays ids g, g+n_slots, ...). */
 int bb_selfplay_begin(bb_engine *e, int n_games, double temp);
@@ -217,8 +235,12 @@ int bb_selfplay_done(bb_engine *e, int *done_out, int *games_finished_out);
  * Returns the number of records written (<= max_records), or a negative status. */
 int bb_examples_fetch(bb_engine *e, int first_game, int n_games, void *records_out, int max_records,
                       int32_t *game_offsets_out /* n_games+1 */, int8_t *winner_out /* n_games */);
-/* device pointer/size of the example store of finished games (for RCCL all-gather) */
-int bb_examples_device(bb_engine *e, void **ptr_out, uint64_t *bytes_out, uint64_t *record_bytes_out);
+/* The example store where it lives, for a device-to-device exchange (the epoch-end RCCL all-gather of (s, pi, z),
+ * SURVEY.md 8e): records_out = device pointer to [max_games][max_plies+1] records of record_bytes each (layout above),
+ * game_hdr_out = device pointer to int32 [max_games][4] = {n_examples, winner, plies, done}; game g's records are the
+ * first n_examples of its row once done != 0.  Valid until bb_destroy; synchronise (bb_synchronize) before reading. */
+int bb_examples_device(bb_engine *e, void **records_out, uint64_t *bytes_out, uint64_t *record_bytes_out,
+                       int32_t **game_hdr_out);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,9 @@ enum { ORC_DYNAMIC = 0, ORC_FIXED = 1 };
 enum { ORC_EVAL_HASH = 0,    /* deterministic synthetic evaluator (parity tests)            */
        ORC_EVAL_NET = 1,     /* residual tower, Network.py:48-64 + NetworkFactory.py:22-183 */
        ORC_EVAL_ROLLOUT = 2, /* base-class MCTS: priors = ones, value = random rollouts     */
-       ORC_EVAL_CALLBACK = 3 /* test hook: evaluator supplied by the caller                 */ };
+       ORC_EVAL_CALLBACK = 3, /* test hook: evaluator supplied by the caller                */
+       ORC_EVAL_CALLBACK_KEYED = 4 /* the same, and the caller is told which (game, node) it evaluates so that its
+                                      getPolicy can mix in that node's prior noise (NetworkFactory.py:176-182) */ };
 
 #define ORC_MAX_CELLS 128
 
@@ -79,6 +81,10 @@ typedef struct {
 /* value in [-1,1] from the side-to-move's perspective, policy[A] as getPolicy would return */
 typedef void (*orc_eval_cb)(void *ctx, const orc_state *st, float *value, float *policy);
 
+/* keyed form: node_serial = order in which the search first reached the node (root = 0), see orc_mcts.c */
+typedef void (*orc_eval_cb2)(void *ctx, const orc_state *st, uint32_t game_id, uint32_t node_serial, float *value,
+                             float *policy);
+
 typedef struct {
     int game;
     int kind;       /* ORC_DYNAMIC / ORC_FIXED */
@@ -93,6 +99,7 @@ typedef struct {
     orc_eval_cb cb;
     void *cb_ctx;
     int priors_ones; /* MCTS.GetPriors default (MCTS.py:346-358): ones -> Priors = legal mask */
+    orc_eval_cb2 cb2; /* ORC_EVAL_CALLBACK_KEYED */
 } orc_cfg;
 
 typedef struct {

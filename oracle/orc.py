@@ -14,7 +14,7 @@ _LIB = os.path.join(_HERE, "liborc.so")
 
 C4, TTT, DC = 0, 1, 2
 DYNAMIC, FIXED = 0, 1
-EVAL_HASH, EVAL_NET, EVAL_ROLLOUT, EVAL_CALLBACK = 0, 1, 2, 3
+EVAL_HASH, EVAL_NET, EVAL_ROLLOUT, EVAL_CALLBACK, EVAL_CALLBACK_KEYED = 0, 1, 2, 3, 4
 GAME_IDS = {"Connect4": C4, "TicTacToe": TTT, "DragonChess": DC}
 
 
@@ -43,13 +43,14 @@ class Net(C.Structure):
 
 
 EVAL_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(State), _FP, _FP)
+EVAL_CB2 = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(State), C.c_uint32, C.c_uint32, _FP, _FP)  # + (game id, node serial)
 
 
 class Cfg(C.Structure):
     _fields_ = [("game", C.c_int), ("kind", C.c_int), ("max_depth", C.c_int), ("evaluator", C.c_int),
                 ("c_puct", C.c_double), ("salt", C.c_uint64), ("seed", C.c_uint64),
                 ("net", C.POINTER(Net)), ("noise_on", C.c_int), ("alpha", C.c_float), ("eps", C.c_float),
-                ("cb", EVAL_CB), ("cb_ctx", C.c_void_p), ("priors_ones", C.c_int)]
+                ("cb", EVAL_CB), ("cb_ctx", C.c_void_p), ("priors_ones", C.c_int), ("cb2", EVAL_CB2)]
 
 
 class Stats(C.Structure):
@@ -209,7 +210,7 @@ def net_forward(w, boards):
 
 # ---- search -----------------------------------------------------------------------------
 def make_cfg(game, kind=DYNAMIC, evaluator=EVAL_HASH, c_puct=0.85, max_depth=10, salt=0, seed=1234,
-             net=None, noise_on=False, alpha=0.2, eps=0.3, cb=None, priors_ones=False):
+             net=None, noise_on=False, alpha=0.2, eps=0.3, cb=None, priors_ones=False, cb2=None):
     c = Cfg()
     c.game, c.kind, c.max_depth, c.evaluator = game, kind, max_depth, evaluator
     c.c_puct, c.salt, c.seed = c_puct, salt, seed
@@ -221,6 +222,9 @@ def make_cfg(game, kind=DYNAMIC, evaluator=EVAL_HASH, c_puct=0.85, max_depth=10,
     if cb is not None:
         c.cb = cb
         c._cb_keep = cb
+    if cb2 is not None:
+        c.cb2 = cb2
+        c._cb2_keep = cb2
     return c
 
 

@@ -61,7 +61,7 @@ float orc_beta_noise(uint64_t key, uint32_t game_id, uint32_t node_serial, uint3
 
 /* numpy add.reduce over a contiguous float64 vector == pairwise sum
  * (numpy/_core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum; checked against numpy 2.2.6
- * in tests/test_oracle_golden.py) */
+ * in tests/test_oracle_games.py::test_np_sum_matches_numpy) */
 double orc_np_sum(const double *a, int n) {
     if (n < 8) {
         double res = 0.;
@@ -127,7 +127,10 @@ typedef struct orc_node {
     int *act;         /* legal action ids, ascending */
     double *prior;    /* Node.Priors restricted to legal ids (illegal ids hold exactly 0) */
     struct orc_node **ch;
-    uint32_t serial;
+    uint32_t serial; /* order of Node.__init__ calls (AddChildren creates every child at once, MCTS.py:136-138) */
+    int32_t visit;   /* order in which searches first REACH nodes (root = 0); -1 = constructed but never reached.  This is
+                      * the node's index in the HIP engine's pool (it materialises a child when a descent first selects it),
+                      * and the key of the node's prior-noise stream in the RNG spec both sides share. */
 } orc_node;
 
 typedef struct arena_blk {
@@ -144,6 +147,7 @@ struct orc_search {
     arena_blk *arena;
     orc_stats stats;
     uint32_t node_serial, sim_serial;
+    int32_t visit_next;
     int value_f32;
     double *tmpA; /* dense scratch, A doubles */
     float *tmpP;  /* dense scratch, A floats */
@@ -204,6 +208,7 @@ static orc_node *node_new(orc_search *s, const orc_state *st) { /* Node.__init__
     memset(n, 0, sizeof(*n));
     n->st = *st;
     n->serial = s->node_serial++;
+    n->visit = -1;
     s->stats.nodes++;
     return n;
 }
@@ -216,6 +221,8 @@ static void evaluate(orc_search *s, const orc_node *n, float *value, float *poli
         orc_hash_eval(c->game, c->salt, &n->st, value, policy);
     } else if (c->evaluator == ORC_EVAL_CALLBACK) {
         c->cb(c->cb_ctx, &n->st, value, policy);
+    } else if (c->evaluator == ORC_EVAL_CALLBACK_KEYED) { /* the caller's getPolicy draws the noise of (game, node) itself */
+        c->cb2(c->cb_ctx, &n->st, s->game_id, (uint32_t)n->visit, value, policy);
     } else if (c->evaluator == ORC_EVAL_NET) {
         int8_t enc[8 * 8 * 17];
         orc_game_encode(c->game, &n->st, enc);
@@ -224,7 +231,7 @@ static void evaluate(orc_search *s, const orc_node *n, float *value, float *poli
         if (c->noise_on && policy) { /* NetworkFactory.py:176-182 */
             float tot = 0.f;
             for (int a = 0; a < s->d.A; a++) {
-                float nz = orc_beta_noise(c->seed, s->game_id, n->serial, (uint32_t)a, c->alpha);
+                float nz = orc_beta_noise(c->seed, s->game_id, (uint32_t)n->visit, (uint32_t)a, c->alpha);
                 policy[a] = (1.0f - c->eps) * policy[a] + c->eps * nz;
                 tot += policy[a];
             }
@@ -408,6 +415,7 @@ static void run_sim(orc_search *s) {
             int k = select_puct(s, node);
             last_action = node->act[k];
             node = node->ch[k];
+            if (node->visit < 0) node->visit = s->visit_next++;
             depth++;
         }
     } else { /* FixedMCTS._findLeaf, FixedMCTS.py:21-34 */
@@ -420,6 +428,7 @@ static void run_sim(orc_search *s) {
             int k = select_puct(s, node);
             last_action = node->act[k];
             node = node->ch[k];
+            if (node->visit < 0) node->visit = s->visit_next++;
             depth++;
         }
     }
@@ -442,7 +451,11 @@ int orc_find_move(orc_search *s, const orc_state *st, double temp, int play_limi
                   double *root_plays) { /* MCTS.FindMove, MCTS.py:146-199 */
     if (play_limit <= 0) return -4; /* ValueError: no stop rule (time limits are host-side) */
     int A = s->d.A;
-    if (!s->root) s->root = node_new(s, st); /* :184-186 */
+    if (!s->root) { /* :184-186 */
+        s->root = node_new(s, st);
+        s->root->visit = 0;
+        s->visit_next = 1;
+    }
     if (!orc_game_equal(s->cfg.game, &s->root->st, st)) return -2; /* assert, :193 */
     int end_plays = s->root->N + play_limit; /* _runMCTS, :297-303 */
     while (s->root->N < end_plays) run_sim(s);
@@ -490,6 +503,7 @@ int orc_move_root(orc_search *s, const orc_state *st) { /* MCTS._moveRoot, MCTS.
     for (int k = 0; k < s->root->nlegal; k++)
         if (orc_game_equal(s->cfg.game, &s->root->ch[k]->st, st)) {
             s->root = s->root->ch[k];
+            if (s->root->visit < 0) s->root->visit = s->visit_next++; /* a move no simulation ever tried */
             return 1;
         }
     return 0;

@@ -31,6 +31,12 @@ def worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     allrec = bdist.allgather_records(make_records(rank))
     np.save(os.path.join(out, f"r{rank}.npy"), allrec.view(np.uint8))
+    # a rank without any finished game still takes part (zero-length shard)
+    some = bdist.allgather_records(make_records(rank)[:0] if rank == 0 else make_records(rank))
+    np.save(os.path.join(out, f"e{rank}.npy"), some.view(np.uint8))
+    # bench.py's reduction: whole-job totals are sums over ranks, the wall time is the slowest rank's
+    sums, maxima = bdist.reduce_totals([100.0 + rank, 7.0 * (rank + 1), 3.0], [1.5 + 0.25 * rank])
+    np.save(os.path.join(out, f"t{rank}.npy"), np.array(sums + maxima))
     dist.destroy_process_group()
 
 
@@ -45,6 +51,9 @@ def test_allgather_two_ranks(tmp_path):
     assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
     ids0, ids1 = set(make_records(0)["game_id"]), set(make_records(1)["game_id"])
     assert not (ids0 & ids1)
+    for r in range(2):
+        assert np.array_equal(np.load(os.path.join(tmp_path, f"e{r}.npy")).view(DT), make_records(1))
+        assert np.array_equal(np.load(os.path.join(tmp_path, f"t{r}.npy")), [201.0, 21.0, 6.0, 1.75])
 
 
 def test_shards_are_disjoint():

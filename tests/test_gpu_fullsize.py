@@ -1,14 +1,17 @@
-"""-m gpu: size-independent properties of the hot path at BASELINE.json's full configs[1] size (Connect4, 4096 concurrent
-games, 800 simulations per move, the default persistent kernel), where the oracle would need hours:
+"""-m gpu: size-independent properties of the hot path at BASELINE.json's full sizes, where the oracle would need hours.
+
+configs[1] (Connect4, 4096 concurrent games, 800 simulations per move, the default persistent kernel) and configs[3]
+(DragonChess, 1024 concurrent games, 400 simulations per move, ply cap 512, the one-wave-per-game kernel on the 161 GB
+edge pool + 27 GB node pool):
 
 * every example's visit counts add up to the root's play count, which is >= playLimit - 1 on a game's first move and grows by
   the re-used subtree afterwards (MCTS.py:146-199 playLimit semantics, _moveRoot :260-282);
 * pi is the normalised visit vector over LEGAL moves only; the terminal example of every finished game has pi = 0 and the
   z of all its examples follows the winner found on the final board (Blackbird.py:253-264);
 * replaying a game's recorded positions with the game kernels reproduces each next position (the move is legal and is the
-  one the visit counts allow: visited at least once);
-* schedule independence: the same games played on 1024 slots (every slot plays several games) are byte-identical to the
-  4096-slot run -- RNG streams are keyed by game id / ply / node, never by slot or time."""
+  one the visit counts allow: visited at least once); DragonChess: the side to move follows W, W, B (DragonChess.py:192-197);
+* schedule independence: the same games played on fewer slots (every slot plays several games) are byte-identical to the
+  run with one slot per game -- RNG streams are keyed by game id / ply / node, never by slot or time."""
 import numpy as np
 import pytest
 
@@ -36,37 +39,41 @@ def _play(n_slots, n_games, plies):
 
 def test_full_size_selfplay_properties():
     n = 4096
-    rec, offs, win, cnt, finished = _play(n, n, 12)   # 12 plies of all 4096 games: 39 M simulations
-    assert cnt["overflow"] == 0 and cnt["sims"] >= n * SIMS * 11
+    rec, offs, win, cnt, finished = _play(n, n, 30)   # 30 steps of all 4096 games: ~100 M simulations, ~3 s
+    assert cnt["overflow"] == 0 and cnt["sims"] >= n * SIMS * 20
+    assert finished >= n // 2 and cnt["games_finished"] == finished  # most games are over after 30+ plies
     game = _lib.GAME_CONNECT4
-    checked_terminal = 0
-    # every record that exists so far
-    for g in range(0, n, 17):                          # a spread of games (python loop cost), all plies of each
+    checked_terminal = checked_records = 0
+    fin = np.nonzero(np.diff(offs) > 0)[0]
+    assert len(fin) == finished
+    for g in fin[::13]:                                # a spread of finished games (python loop cost), all plies of each
         r = rec[offs[g]:offs[g + 1]]
-        if len(r) == 0:
-            continue
         states = np.ascontiguousarray(r["state"]).view(_lib.STATE_DTYPE[game]).reshape(len(r), -1)
         legal = _lib.game_legal(game, states)
         vis = r["visits"][:, :7].astype(np.int64)
         tot = r["total"].astype(np.int64)
         nonterm = vis.sum(1) > 0
+        assert nonterm[:-1].all() and not nonterm[-1]  # exactly one terminal example (pi = 0), the last one
         assert np.array_equal(vis.sum(1)[nonterm], tot[nonterm])
         assert tot[0] >= SIMS - 1                      # first move: playLimit simulations, the first one expands the root
+        assert (tot[:-1] >= SIMS - 1).all()            # later moves: playLimit more on top of the re-used subtree
         assert (np.diff(r["ply"].astype(np.int64)) == 1).all() and r["ply"][0] == 0
         assert ((vis > 0) <= (legal > 0)).all()        # visits only on legal moves
+        assert (r["player"][:-1] == 1 + (np.arange(len(r) - 1) % 2)).all()  # players alternate from player 1
         # the recorded next position is reachable by a visited move
         for k in range(len(r) - 1):
             cand = np.nonzero(vis[k])[0]
             nxt, status = _lib.game_apply(game, np.repeat(states[k:k + 1], len(cand), 0), cand.astype(np.int32))
             assert any(status[i] == 0 and nxt[i].tobytes() == states[k + 1].tobytes() for i in range(len(cand)))
-        if win[g] >= 0 and not nonterm[-1]:            # finished game: terminal example, z by winner
-            checked_terminal += 1
-            w = int(_lib.game_winner(game, states[-1:])[0])
-            assert w == win[g]
-            z = r["z"].astype(np.int64)
-            expect = np.where(w == 0, 0, np.where(r["player"] == w, 1, -1))
-            assert np.array_equal(z, expect)
-    assert finished >= 0 and checked_terminal >= 0
+        # finished game: the final board decides z for every example (Blackbird.py:260-264)
+        w = int(_lib.game_winner(game, states[-1:])[0])
+        assert w == win[g] and w >= 0
+        z = r["z"].astype(np.int64)
+        expect = np.where(w == 0, 0, np.where(r["player"] == w, 1, -1))
+        assert np.array_equal(z, expect)
+        checked_terminal += 1
+        checked_records += len(r)
+    assert checked_terminal >= 150 and checked_records >= 150 * 8, (checked_terminal, checked_records)
 
 
 def test_results_do_not_depend_on_the_slot_count():
@@ -76,3 +83,99 @@ def test_results_do_not_depend_on_the_slot_count():
     assert a[4] == b[4] == 1536
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert a[0].tobytes() == b[0].tobytes()
+
+
+# ---- BASELINE configs[3]: DragonChess, 1024 concurrent games x 400 simulations per move ---------------------------
+DC_SIMS = 400
+
+
+def _play_dc(n_slots, n_games, prefill_plies, plies, max_plies=512, first_id=0):
+    game = _lib.GAME_DRAGONCHESS
+    eng = _lib.Engine(game, n_slots=n_slots, sims_per_move=DC_SIMS, evaluator=_lib.EVAL_NET, seed=777, noise_on=True,
+                      alpha=0.2, epsilon=0.3, max_games=n_games, max_plies=max_plies, first_game_id=first_id)
+    eng.load_weights(W.flatten(W.init_weights(17, 16, 4, 16, 4032, seed=0)))
+    mode = eng.selfplay_mode()
+    eng.selfplay_begin(n_games, 1.0)
+    if prefill_plies:
+        eng.set_sims_per_move(6)                      # a quick stretch of weak play so that games END inside the test
+        eng.selfplay_step(prefill_plies)
+        eng.set_sims_per_move(DC_SIMS)
+    for _ in range(plies):
+        eng.selfplay_step(1)
+    eng.synchronize()
+    cnt = eng.counters()
+    done, finished = eng.selfplay_done()
+    rec, offs, win = eng.fetch_examples()
+    eng.close()
+    return rec, offs, win, cnt, finished, mode
+
+
+def _dc_pi(r, k):
+    pi = np.zeros(4032, dtype=np.int64)
+    n = int(r["n_children"][k])
+    pi[r["action"][k][:n]] = r["visits"][k][:n]
+    return pi
+
+
+def test_dragonchess_full_size_properties():
+    """configs[3] at full size: 1024 waves on 1024 slots, pools of 512 plies x 400 simulations per slot (188 GB), slot
+    recycling when games end.  300 plies of weak play bring most games to their end; then 6 plies at the full 400
+    simulations per move are what the checks below look at (records whose root play count says 400-strength search)."""
+    n = 1024
+    rec, offs, win, cnt, finished, mode = _play_dc(n, 2 * n, 300, 6)
+    assert mode == 5 and cnt["overflow"] == 0
+    assert cnt["sims"] >= 6 * n * DC_SIMS * 0.9          # the six full-strength plies dominate the count
+    assert finished >= 200, finished                     # kings do get captured under weak play
+    game = _lib.GAME_DRAGONCHESS
+    fin = np.nonzero(np.diff(offs) > 0)[0]
+    # every record of every finished game at once: the visits of the listed children add up to the root's play count
+    live = np.arange(rec["visits"].shape[1])[None, :] < rec["n_children"][:, None]
+    assert np.array_equal((rec["visits"] * live).sum(1), rec["total"])
+    strong = (rec["n_children"] > 0) & (rec["total"] >= DC_SIMS - 1)   # searched with the full 400 simulations
+    assert strong.sum() >= 20, int(strong.sum())                        # games that ended during the six strong plies
+    checked_games = capped = 0
+    for g in fin[::7]:
+        r = rec[offs[g]:offs[g + 1]]
+        states = np.ascontiguousarray(r["state"])
+        legal = _lib.game_legal(game, states)
+        assert (np.diff(r["ply"].astype(np.int64)) == 1).all() and r["ply"][0] == 0 and (r["game_id"] == g).all()
+        tot = r["total"].astype(np.int64)
+        # W, W, B turn order (DragonChess.py:192-197), checked on the recorded side to move
+        pl = r["player"].astype(np.int64)
+        assert (pl[:-1] == np.array([1, 1, 2])[np.arange(len(r) - 1) % 3]).all()
+        for k in range(len(r) - 1):
+            pi = _dc_pi(r, k)
+            nch = int(r["n_children"][k])
+            assert nch == int(legal[k].sum()) and pi.sum() == tot[k] and tot[k] >= 5
+            assert ((pi > 0) <= (legal[k] > 0)).all()
+            assert sorted(r["action"][k][:nch].tolist()) == np.nonzero(legal[k])[0].tolist()  # one child per legal move
+        # replay: the next recorded position follows from a visited move (spot-check three plies per game)
+        for k in sorted(set([0, (len(r) - 1) // 2, len(r) - 2]) & set(range(len(r) - 1))):
+            cand = np.nonzero(_dc_pi(r, k))[0]
+            nxt, status = _lib.game_apply(game, np.repeat(states[k:k + 1], len(cand), 0), cand.astype(np.int32))
+            assert any(status[i] == 0 and nxt[i][:70].tobytes() == states[k + 1][:70].tobytes() for i in range(len(cand)))
+        # terminal example + z
+        assert int(r["n_children"][-1]) == 0 and tot[-1] == 0
+        w = int(_lib.game_winner(game, states[-1:])[0])
+        if w < 0:                                        # ply cap reached (documented deviation: z = 0)
+            assert len(r) == 513 and (r["z"] == 0).all() and win[g] == -1
+            capped += 1
+        else:
+            assert w == win[g] and w in (1, 2)           # never a draw: win by king capture (DragonChess.py:161-167)
+            assert np.array_equal(r["z"].astype(np.int64), np.where(r["player"] == w, 1, -1))
+        checked_games += 1
+    assert checked_games >= 25, checked_games
+
+
+def test_dragonchess_results_do_not_depend_on_the_slot_count():
+    """1024 games on 1024 slots vs the same games on 256 slots (4 games per slot, 4x smaller pools): byte-identical
+    records.  Ply cap 24 and full 400-simulation searches throughout, so every game ends (at the cap) and is compared."""
+    a = _play_dc(1024, 1024, 0, 24, max_plies=24)
+    b = _play_dc(256, 1024, 0, 96, max_plies=24)
+    assert a[5] == b[5] == 5 and a[3]["overflow"] == 0 and b[3]["overflow"] == 0
+    assert a[4] == b[4] == 1024
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert a[0].tobytes() == b[0].tobytes()
+    assert a[3]["sims"] == b[3]["sims"] and a[3]["sum_depth"] == b[3]["sum_depth"]
+    r = a[0]
+    assert (r["total"][r["n_children"] > 0] >= DC_SIMS - 1).all()  # every search had the full 400 simulations
