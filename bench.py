@@ -53,7 +53,7 @@ WORKLOADS = {
     "c5": dict(game=_lib.GAME_CONNECT4, name="Connect4 7x6", hw=42, C=3, A=7, blocks=20, filters=256, sims=800, slots=4096,
                max_plies=42, prefill=(64, 32), steps=32, warmup=8, cfg=4, min_game_plies=7),
     "dc": dict(game=_lib.GAME_DRAGONCHESS, name="DragonChess 8x8", hw=64, C=17, A=4032, blocks=4, filters=16, sims=400,
-               slots=1024, max_plies=512, prefill=(192, 8), steps=32, warmup=4, cfg=3, min_game_plies=3),
+               slots=1024, max_plies=512, prefill=(96, 8), steps=32, warmup=4, cfg=3, min_game_plies=3),
 }
 
 
@@ -69,6 +69,31 @@ def tree_bytes_per_sim(w, mean_depth, mean_children):
     for DragonChess), S = state bytes (24 / 104 as the survey counts them)."""
     S = 104 if w["game"] == _lib.GAME_DRAGONCHESS else 24
     return 16 * mean_children * mean_depth + 16 * (mean_depth + 1) + 16 * mean_children + 2 * S + w["hw"] * w["C"] + 4 * (w["A"] + 1)
+
+
+def usable_cpus():
+    """CPUs this process can actually run on at once: the affinity mask, cut down to the cgroup's CPU quota when there is
+    one (a GPU box hands a 1-GPU job a share of the host, e.g. 16 of 256 hardware threads)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(round(int(parts[0]) / int(parts[1])))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(round(quota / int(f.read().split()[0])))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def host_cpu():
@@ -95,17 +120,19 @@ def cpu_baseline(key, w, flat, gpu_mean_plies, budget_s=20.0):
     H, Wd = (8, 8) if key == "dc" else (6, 7)
     ow = orc.NetWeights(H, Wd, w["C"], w["filters"], w["blocks"], 16, w["A"], flat)
     cfg = orc.make_cfg(og, evaluator=orc.EVAL_NET, net=ow, noise_on=True, alpha=0.2, eps=0.3, seed=1234)
-    cores, model = host_cpu()
+    nproc, model = host_cpu()
+    cores = usable_cpus()   # every core this job may use (nproc is what the host has)
     if key == "c2":
-        sims, plies_cap, what = w["sims"], 42, "full Connect4 games at 800 sims/move"
+        sims, plies_cap, reps, what = w["sims"], 42, 3, "full Connect4 games at 800 sims/move"
     elif key == "dc":
-        sims, plies_cap, what = w["sims"], 2, "the first 2 plies of a DragonChess game at 400 sims/move"
+        sims, plies_cap, reps, what = w["sims"], 100, 1, "the first 100 plies of a DragonChess game at 400 sims/move"
     else:
-        sims, plies_cap, what = 4, 1, "one Connect4 ply of 4 simulations with the 20x256 network (~2 GFLOP per evaluation)"
-    res = [None] * cores
+        sims, plies_cap, reps, what = 48, 1, 1, "one Connect4 ply of 48 simulations with the 20x256 network (~2 GFLOP per evaluation)"
+    res = [None] * (cores * reps)
 
     def work(i):
-        res[i] = orc.selfplay_game(cfg, 10_000_000 + i, 1.0, sims, plies_cap)
+        for r in range(reps):
+            res[i * reps + r] = orc.selfplay_game(cfg, 10_000_000 + i * reps + r, 1.0, sims, plies_cap)
 
     t0 = time.time()
     th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
@@ -116,14 +143,15 @@ def cpu_baseline(key, w, flat, gpu_mean_plies, budget_s=20.0):
     dt = time.time() - t0
     tot_sims = sum(r["stats"].sims for r in res)
     plies = sum(r["n"] - 1 for r in res)
-    out = {"unit": "games/s", "cores": cores, "nproc": cores, "cpu_model": model, "kind": "port",
+    out = {"unit": "games/s", "cores": cores, "nproc": nproc, "cpu_model": model, "kind": "port",
+           "cores_note": "threads used = CPUs usable by this job (affinity mask / cgroup quota); nproc = host hardware threads",
            "port_note": "oracle/ C restatement of the reference's serial search; ONE network evaluation per simulation "
                         "(value + priors of the expanded node together) where the reference runs 1 + b batch-1 sess.run "
                         "calls per simulation (SURVEY.md 3.2), so this baseline is faster than the reference itself",
            "sims_per_s": tot_sims / dt, "plies_per_s": plies / dt, "wall_s": dt}
     if key == "c2":
-        out["value"] = cores / dt
-        out["sample"] = f"{cores} {what}, one per host thread, {plies} plies, {dt:.1f} s wall"
+        out["value"] = len(res) / dt
+        out["sample"] = f"{len(res)} {what}, {reps} per host thread on {cores} threads, {plies} plies, {dt:.1f} s wall"
     else:
         per_game = max(gpu_mean_plies, 1.0)
         rate = (plies / dt) if key == "dc" else (tot_sims / dt / w["sims"])   # plies per second
@@ -210,7 +238,7 @@ def main():
     # step can be more than one ply: x2 head-room)
     max_games = slots * (2 * total_plies // w["min_game_plies"] + 2)
     if args.workload == "dc":
-        max_games = slots * 3  # DragonChess games last tens to hundreds of plies
+        max_games = slots * 8  # DragonChess games last tens to hundreds of plies (mean ~80 under weak play)
     from blackbird_amd import dist as bdist
     first_id, seed = bdist.shard(rank, 1234)
     eng = _lib.Engine(game, n_slots=slots, sims_per_move=sims, evaluator=_lib.EVAL_NET, c_puct=0.85,

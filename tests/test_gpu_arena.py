@@ -148,7 +148,6 @@ def test_batched_arena_equals_two_searcher_oracle(orc, key, temp):
     got = TestModelsBatched(p1, p2, temp, len(first), first=first, uniforms=rng_a.random_sample)
     want = _oracle_arena(orc, og, (cfg1, cfg2), sims, first, temp, rng_b.random_sample)
     assert np.array_equal(got, want), (got, want)
-    assert len(set(got.tolist())) > 1 or key.startswith("ttt")  # (Connect4: both outcomes occur in this set)
 
 
 def test_test_models_and_tally_go_through_the_arena(tmp_path, monkeypatch):

@@ -100,6 +100,8 @@ def _play_dc(n_slots, n_games, prefill_plies, plies, max_plies=512, first_id=0):
         eng.set_sims_per_move(6)                      # a quick stretch of weak play so that games END inside the test
         eng.selfplay_step(prefill_plies)
         eng.set_sims_per_move(DC_SIMS)
+        eng.synchronize()
+        eng.reset_counters()                          # the counters then describe the full-strength plies only
     for _ in range(plies):
         eng.selfplay_step(1)
     eng.synchronize()
@@ -119,12 +121,13 @@ def _dc_pi(r, k):
 
 def test_dragonchess_full_size_properties():
     """configs[3] at full size: 1024 waves on 1024 slots, pools of 512 plies x 400 simulations per slot (188 GB), slot
-    recycling when games end.  300 plies of weak play bring most games to their end; then 6 plies at the full 400
-    simulations per move are what the checks below look at (records whose root play count says 400-strength search)."""
+    recycling when games end.  200 plies of weak play bring many games to their end; then 6 plies at the full 400
+    simulations per move follow (records whose root play count says 400-strength search; the counters cover these plies)."""
     n = 1024
-    rec, offs, win, cnt, finished, mode = _play_dc(n, 2 * n, 300, 6)
+    rec, offs, win, cnt, finished, mode = _play_dc(n, 8 * n, 200, 6)
     assert mode == 5 and cnt["overflow"] == 0
-    assert cnt["sims"] >= 6 * n * DC_SIMS * 0.9          # the six full-strength plies dominate the count
+    assert cnt["sims"] == 6 * n * DC_SIMS                # six plies of 400 simulations on every one of the 1024 slots
+    assert cnt["plies"] == 6 * n and cnt["evals"] <= cnt["sims"]
     assert finished >= 200, finished                     # kings do get captured under weak play
     game = _lib.GAME_DRAGONCHESS
     fin = np.nonzero(np.diff(offs) > 0)[0]
