@@ -503,7 +503,7 @@ extern "C" int bb_selfplay_mode(bb_engine *e) {
     // the persistent kernels carry a 16-filter network of at most MEGA_RMAX blocks in LDS; anything else runs as rounds
     const bool fits = !e->has_weights || (!e->general_net && e->net.R <= MEGA_RMAX && e->net.head_floats <= MEGA_HEAD_FLOATS);
     if (e->mega && fits) return 3;
-    if (e->dc_fused && (!e->has_weights || !e->general_net)) return 5;
+    if (e->dc_fused && (!e->has_weights || (!e->general_net && e->net.head_floats <= DC_HEAD_FLOATS))) return 5;
     return e->async_selfplay ? 1 : 0;
 }
 
@@ -1183,7 +1183,7 @@ extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
     GAME_SWITCH(e->cfg.game, {
         if (e->async_selfplay) return selfplay_rounds_async<G>(e, plies * e->sims_now);
         if constexpr (G::GID == BB_GAME_DRAGONCHESS) {
-            if (e->dc_fused && e->has_weights && !e->general_net) {
+            if (e->dc_fused && e->has_weights && !e->general_net && e->net.head_floats <= DC_HEAD_FLOATS) {
                 // at most 16 plies per launch (a launch is plies x sims x ~70 us long; nothing inside can spin)
                 for (int done = 0; done < plies; done += 16) {
                     const int now = plies - done < 16 ? plies - done : 16;

@@ -11,6 +11,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// A pointer the caller KNOWS to be LDS (or global), re-derived through an explicit address-space cast: the compiler's
+// address-space inference then turns the accesses behind it into ds_* (global_*) instructions.  Through a generic pointer
+// every access is a flat_* instruction -- it takes the LDS and the memory path, counts on both vmcnt and lgkmcnt, and its
+// LDS round trip is several times a ds_read's.  Device functions that are not inlined into the kernel that owns the
+// __shared__ array (the out-of-line phase functions of mega_dc.hip.h) only see generic pointers unless told.
+template <class T>
+__device__ __forceinline__ T *as_lds(T *p) {
+#if __HIP_DEVICE_COMPILE__
+    __builtin_assume(__builtin_amdgcn_is_shared((const void *)p));
+#endif
+    return p;
+}
+template <class T>
+__device__ __forceinline__ T *as_global(T *p) {
+#if __HIP_DEVICE_COMPILE__
+    __builtin_assume(!__builtin_amdgcn_is_shared((const void *)p) && !__builtin_amdgcn_is_private((const void *)p));
+#endif
+    return p;
+}
+
 struct GridState {
     uint64_t p1, p2;
 };

@@ -11,55 +11,87 @@
 #include "net.hip.h"
 #include "tree_dc.hip.h"
 
+#define DC_HEAD_FLOATS 12288 // packed head parameters (2 x 4032 policy kernel + 4032 bias + the small ones) kept in LDS: 48 KB
+
 // The three phases are separate functions on purpose: inlined into one loop body the compiler keeps every phase's
 // address arithmetic alive across the others (256 VGPRs + 402 spilled, slower than the launches it replaces).
-__device__ __attribute__((noinline)) void dc_fused_tree(const TreeDev &d, const DCEdges &E, int g, int lane, double *tl) {
-    dc_phase_apply(d, E, g, lane, tl);
+__device__ __attribute__((noinline)) void dc_fused_tree(const TreeDev &d_, const DCEdges &E_, int g, int lane, float *tl, const DCHeadLocal *hl) {
+    const TreeDev &d = *as_lds(&d_); // everything the kernel hands over lives in its LDS (see as_lds)
+    const DCEdges &E = *as_lds(&E_);
+    tl = as_lds(tl);
+    hl = as_lds(hl);
+    dc_phase_apply(d, E, g, lane, tl, hl);
     __threadfence_block();
     dc_phase_select(d, E, g, lane, tl);
     __threadfence_block();
 }
-__device__ __attribute__((noinline)) void dc_fused_net(const NetDev &nd, const TreeDev &d, const int *slot, float *nl, int noise_on) {
-    (void)noise_on; // the prior noise of a wide game is mixed in at expansion (dc_expand), over the legal moves only
-    net_body<DragonChess, 1>(nd, 1, 0, slot, nl, (const DCState *)d.leaf_state, nullptr, d.leaf_game_id, d.leaf_serial, 0,
-                             d.eval_value, nullptr, d.eval_policy, DragonChess::A);
+// The network for the wave's own leaf.  Nothing 4032-wide leaves the wave: the policy head is reduced to (R0, R1, max,
+// 1 / sum exp) in `hl` (net.hip.h: WideHead) and the expansion of the next tree phase computes the probabilities of its
+// legal moves from those and the head weights in LDS -- instead of a 16 KB policy row written to and gathered from
+// memory, and 189 L2 loads per lane for the head weights, per evaluation.  (The prior noise of a wide game is mixed in
+// at expansion, over the legal moves only: dc_expand.)
+__device__ __attribute__((noinline)) void dc_fused_net(const NetDev &nd_, const TreeDev &d_, const int *slot, float *nl, DCHeadLocal *hl) {
+    const NetDev &nd = *as_lds(&nd_);
+    const TreeDev &d = *as_lds(&d_);
+    slot = as_lds(slot);
+    nl = as_lds(nl);
+    hl = as_lds(hl);
+    net_body<DragonChess, 1, true>(nd, 1, 0, slot, nl, (const DCState *)d.leaf_state, nullptr, d.leaf_game_id, d.leaf_serial, 0,
+                             nullptr, nullptr, nullptr, DragonChess::A, true, nullptr, &hl->h);
     __threadfence_block();
 }
-__device__ __attribute__((noinline)) void dc_fused_move(const TreeDev &d, const DCEdges &E, int g, int lane, double *tl) {
-    dc_selfplay_move_body(d, E, g, lane, tl);
+__device__ __attribute__((noinline)) void dc_fused_move(const TreeDev &d_, const DCEdges &E_, int g, int lane, float *tl, const DCHeadLocal *hl) {
+    const TreeDev &d = *as_lds(&d_);
+    const DCEdges &E = *as_lds(&E_);
+    tl = as_lds(tl);
+    hl = as_lds(hl);
+    dc_selfplay_move_body(d, E, g, lane, tl, hl);
     __threadfence_block();
 }
 
 __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdges E_arg, NetDev nd_arg, int plies, int sims, int noise_on) {
     using NG = NetGeom<DragonChess, 1>;
-    // the tree's scratch (the 4032-double policy image) and the network's activations are never live together
-    constexpr int TREE_BYTES = DC_LDS_DOUBLES * 8, NET_BYTES = NG::WAVE_FLOATS * 4;
+    // the tree's scratch (the 4032-float policy image) and the network's activations are never live together
+    constexpr int TREE_BYTES = DC_LDS_FLOATS * 4, NET_BYTES = NG::WAVE_FLOATS * 4;
     constexpr int WAVE_BYTES = ((TREE_BYTES > NET_BYTES ? TREE_BYTES : NET_BYTES) + 15) / 16 * 16;
-    static_assert(4 * WAVE_BYTES + 64 <= 163840, "four waves' scratch must fit the 160 KiB LDS");
+    static_assert(4 * WAVE_BYTES + DC_HEAD_FLOATS * 4 + 1024 <= 163840, "four waves' scratch and the head weights must fit the 160 KiB LDS");
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[4][WAVE_BYTES];
+    __shared__ __attribute__((aligned(16))) float s_head[DC_HEAD_FLOATS];
     __shared__ int myslot[4];
+    __shared__ DCHeadLocal s_hl[4];
     // the phase functions take the three descriptor structs by reference: from LDS copies (made once) rather than from a
     // per-lane scratch copy of the kernel arguments -- a lone wave feels every round trip of its ~100 field loads per call
     __shared__ TreeDev s_d;
     __shared__ DCEdges s_E;
     __shared__ NetDev s_nd;
+    for (int i = threadIdx.x; i < nd_arg.head_floats; i += blockDim.x) s_head[i] = nd_arg.head[i]; // (host: head_floats <= DC_HEAD_FLOATS)
     if (threadIdx.x == 0) {
         s_d = d_arg;
         s_E = E_arg;
         s_nd = nd_arg;
+        s_nd.head = s_head;
+    }
+    if (threadIdx.x < 4) {
+        using LP = const __attribute__((address_space(3))) float *;
+        s_hl[threadIdx.x].pdk = (LP)s_head + nd_arg.off_pdk;
+        s_hl[threadIdx.x].pdb = (LP)s_head + nd_arg.off_pdb;
+        s_hl[threadIdx.x].h = WideHead{0.f, 0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
+    (void)noise_on; // E.noise_on carries it to the expansion
     const TreeDev &d = s_d;
     const DCEdges &E = s_E;
     const NetDev &nd = s_nd;
     const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (g >= d.n_slots) return;
-    double *tl = (double *)lds_all[wv];
+    float *tl = (float *)lds_all[wv];
     float *nl = (float *)lds_all[wv];
+    DCHeadLocal *hl = &s_hl[wv];
     if (lane == 0) myslot[wv] = g;
 #ifdef BB_STAMPS
-    double *lds = tl; // DST's accumulator sits past the policy image, outside the network's activations
-    if (lane < 16) ((unsigned long long *)(lds + 4032))[lane] = 0;
+    float *lds = tl; // DST's accumulator sits past the policy image and the network's activations
+    static_assert(DC_STAMP_OFF >= NG::WAVE_FLOATS, "stamp words must survive the network's zeroing of its scratch");
+    if (lane < 16) ((unsigned long long *)(lds + DC_STAMP_OFF))[lane] = 0;
 #endif
     __threadfence_block();
     for (int p = 0; p < plies; p++) {
@@ -68,22 +100,22 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
 #ifdef BB_STAMPS
             long long c0 = clock64();
 #endif
-            dc_fused_tree(d, E, g, lane, tl);
+            dc_fused_tree(d, E, g, lane, tl, hl);
 #ifdef BB_STAMPS
             long long c1 = clock64();
 #endif
             if (d.pend_leaf[g] >= 0) // (uniform) a leaf was posted: evaluate it right here
-                dc_fused_net(nd, d, &myslot[wv], nl, noise_on);
+                dc_fused_net(nd, d, &myslot[wv], nl, hl);
 #ifdef BB_STAMPS
             DST(0, c1 - c0);          // tree phases (tools/dc_stamps.py)
             DST(2, clock64() - c1);   // network
             DST(4, 1);
 #endif
         }
-        dc_fused_move(d, E, g, lane, tl);
+        dc_fused_move(d, E, g, lane, tl, hl);
     }
 #ifdef BB_STAMPS
     if (lane == 0 && d.stamps)
-        for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[(size_t)(g & 63) * 16 + i], ((unsigned long long *)(lds + 4032))[i]);
+        for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[(size_t)(g & 63) * 16 + i], ((unsigned long long *)(lds + DC_STAMP_OFF))[i]);
 #endif
 }

@@ -66,6 +66,76 @@ struct NetGeom {
     static_assert(LDS_BYTES <= 163840, "activations must fit the 160 KiB LDS");
 };
 
+// ---- wide policy head (DragonChess, A = 4032) ---------------------------------------------------------------------
+// logits[a] = sum_p (r1[p]*k1[a] + (r0[p]*k0[a] + b[a])) = k1[a]*sum(r1) + k0[a]*sum(r0) + HW*b[a]: the spatial sum is
+// taken once per position ("a global-sum-pool then a 2xA GEMV"), so the whole 4032-wide policy of a
+// position is a function of TWO numbers (R0, R1); it differs from the oracle's per-pixel order only in rounding (1e-5,
+// tests/test_gpu_net.py).  The softmax runs on the hardware exp2 (v_exp_f32 on (x - m) * log2 e) with one reciprocal per
+// wave.  These pieces are shared by the dense form below (bb_net_eval, lock-step search: the 4032 probabilities go to
+// memory) and the compact form of the one-wave-per-game kernel (mega_dc.hip.h: only max and 1/sum are kept and the
+// expansion evaluates the probabilities of its ~20 legal moves itself) so that both give the same bits.
+struct WideHead { // what is left of an evaluation once the 4032-wide row is not materialised
+    float value, R0, R1, m, inv;
+};
+template <int HW>
+__device__ __forceinline__ float wide_logit(float R0, float R1, float k0, float k1, float b) {
+    return __builtin_fmaf(R1, k1, __builtin_fmaf(R0, k0, (float)HW * b));
+}
+__device__ __forceinline__ float wide_expterm(float l, float m) { return __builtin_amdgcn_exp2f((l - m) * 1.44269504088896340736f); }
+template <int HW>
+__device__ __forceinline__ float wide_prob(const WideHead &h, float k0, float k1, float b) {
+    return wide_expterm(wide_logit<HW>(h.R0, h.R1, k0, k1, b), h.m) * h.inv;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// max and 1 / sum(exp) of the A logits, lanes striding the actions (lane + 64 k, k ascending; partial sums per lane in
+// that order, then the xor butterflies) -- the order the dense form uses.  PK: pointer type of the head weights
+// (generic, or address_space(3) when the caller keeps them in LDS).
+template <int A, int HW, class PK>
+__device__ __forceinline__ void wide_head_stats(WideHead &h, PK pdk, PK pdb, int lane) {
+    static_assert(A % 64 == 0, "every lane owns exactly A / 64 actions: the loops below carry no bounds test");
+    constexpr int NPL = A / 64, UB = 9; // UB actions per batch: their 3 x UB weights are requested together, then consumed
+    static_assert(NPL % UB == 0, "whole batches");
+    float m = -INFINITY;
+    for (int k0 = 0; k0 < NPL; k0 += UB) {
+        float w0[UB], w1[UB], wb[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int a = lane + 64 * (k0 + u);
+            w0[u] = pdk[a];
+            w1[u] = pdk[A + a];
+            wb[u] = pdb[a];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u++) m = fmaxf(m, wide_logit<HW>(h.R0, h.R1, w0[u], w1[u], wb[u]));
+    }
+    m = wave_max_f32(m);
+    float tot = 0.f;
+    for (int k0 = 0; k0 < NPL; k0 += UB) {
+        float w0[UB], w1[UB], wb[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int a = lane + 64 * (k0 + u);
+            w0[u] = pdk[a];
+            w1[u] = pdk[A + a];
+            wb[u] = pdb[a];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u++) tot += wide_expterm(wide_logit<HW>(h.R0, h.R1, w0[u], w1[u], wb[u]), m); // (k ascending: the dense form's order)
+    }
+    tot = wave_sum_f32(tot);
+    h.m = m;
+    h.inv = 1.0f / tot;
+}
+
 // Everything after the two 1x1 head convolutions, shared by the fused F=16 kernels and the general-F path
 // (gnet.hip.h): rv / rp hold relu(bn(conv)) per pixel of the PW positions, sd / lg are scratch.
 // NetworkFactory.py:100-183: dense_1 per pixel -> reduce_sum -> ReLU -> dense_2 -> tanh;  policy dense on the
@@ -74,7 +144,8 @@ template <class G, int PW>
 __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0, const int *slot_list, const float *rv,
                                               const float *rp, float *sd, float *lg, const uint32_t *game_id,
                                               const int32_t *serial, int noise, float *value_out, float *logits_out,
-                                              float *policy_out, int pstride, const float *noise_in) {
+                                              float *policy_out, int pstride, const float *noise_in,
+                                              WideHead *compact = nullptr) {
     using NG = NetGeom<G, PW>;
     constexpr int A = NG::A, HW = NG::HW;
     const int lane = threadIdx.x & 63;
@@ -102,27 +173,42 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
             }
         }
     }
+#ifdef BB_STAMPS_NET
+    long long _ns = clock64();
+#endif
     if constexpr (A > 64) {
-        // wide policy (DragonChess, A = 4032): logits[a] = sum_p (r1[p]*k1[a] + (r0[p]*k0[a] + b[a])) in the
-        // oracle's pixel order, lanes stride the actions; softmax max/sum are wave reductions.
+        // wide policy (DragonChess, A = 4032): see the helpers above
         const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
         const int D = nd.D;
         const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
         for (int pp = 0; pp < PW; pp++) {
             if (pos0 + pp >= n) break;
             int pos = OI(pos0 + pp);
-            float *outp = policy_out ? policy_out + (size_t)pos * pstride : nullptr;
-            // sum_p (r1[p]*k1 + r0[p]*k0 + b) == k1*sum(r1) + k0*sum(r0) + HW*b: the spatial sum is taken once per
-            // position ("a global-sum-pool then a 2xA GEMV"); differs from the oracle's
-            // per-pixel order only in rounding (checked to 1e-5 in tests/test_gpu_net.py)
-            float R0 = 0.f, R1 = 0.f;
+            WideHead h;
+            h.R0 = 0.f;
+            h.R1 = 0.f;
             for (int p = 0; p < HW; p++) {
-                R0 += rp[2 * (pp * HW + p)];
-                R1 += rp[2 * (pp * HW + p) + 1];
+                h.R0 += rp[2 * (pp * HW + p)];
+                h.R1 += rp[2 * (pp * HW + p) + 1];
             }
+            {
+                float e = d2b[0];
+                for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(sd[pp * D + dd], d2k[dd], e);
+                h.value = tanhf(e);
+            }
+            if (lane == 0 && value_out) value_out[pos] = h.value;
+            NSTAMP(6);
+            if (compact) { // the caller evaluates the few probabilities it needs from (R0, R1, m, 1/sum)
+                // contract: a caller that asks for the compact form keeps nd.head in LDS (mega_dc.hip.h) -- the 3 x 4032
+                // head weights are then read with ds_read instead of flat loads
+                using LP = const __attribute__((address_space(3))) float *;
+                wide_head_stats<A, HW>(h, (LP)pdk, (LP)pdb, lane);
+                if (lane == 0) compact[pp] = h;
+                continue;
+            }
+            float *outp = policy_out ? policy_out + (size_t)pos * pstride : nullptr;
             // the (A+63)/64 logits of a lane stay in registers from the GEMV to the normalised store: one pass over the
-            // head weights (L2-resident, shared by all positions) and ONE 16 KB write per position, instead of three
-            // writes and two re-reads of the policy row
+            // head weights (L2-resident, shared by all positions) and ONE 16 KB write per position
             constexpr int NPL = (A + 63) / 64;
             float sv[NPL];
             float m = -INFINITY;
@@ -130,29 +216,23 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
             for (int k = 0; k < NPL; k++) {
                 const int a = lane + 64 * k;
                 if (a < A) {
-                    sv[k] = __builtin_fmaf(R1, pdk[A + a], __builtin_fmaf(R0, pdk[a], (float)HW * pdb[a]));
+                    sv[k] = wide_logit<HW>(h.R0, h.R1, pdk[a], pdk[A + a], pdb[a]);
                     if (logits_out) logits_out[(size_t)pos * A + a] = sv[k];
                     m = fmaxf(m, sv[k]);
                 } else {
                     sv[k] = -INFINITY;
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            m = wave_max_f32(m);
             if (outp) {
-                // 4032 exponentials and quotients per position: the hardware exp2 (v_exp_f32 on (x - m) * log2 e) and one
-                // reciprocal per wave instead of library expf and 63 divisions per lane -- ~1.7 k fewer vector instructions
-                // of the evaluation's ~13 k.  Relative error ~1e-6, inside the 1e-5 the network outputs are held to
-                // (tests/test_gpu_net.py); every DragonChess path shares this code, so they stay identical to each other.
                 float tot = 0.f;
 #pragma unroll
                 for (int k = 0; k < NPL; k++)
                     if (lane + 64 * k < A) {
-                        sv[k] = __builtin_amdgcn_exp2f((sv[k] - m) * 1.44269504088896340736f);
+                        sv[k] = wide_expterm(sv[k], m);
                         tot += sv[k];
                     }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+                tot = wave_sum_f32(tot);
                 float inv = 1.0f / tot;
                 if (noise) { // getPolicy through bb_net_eval: policy = (1-eps)*softmax + eps*Beta(alpha,1-alpha); policy /= sum(policy)
                     // (the tree paths pass noise = 0 for wide games: they mix the draws in at expansion, tree_dc.hip.h)
@@ -164,18 +244,12 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
                             sv[k] = (1.0f - nd.eps) * (sv[k] * inv) + nd.eps * bb_beta_noise(nd.seed, gid, ser, (uint32_t)(lane + 64 * k), nd.alpha);
                             t2 += sv[k];
                         }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) t2 += __shfl_xor(t2, o, 64);
+                    t2 = wave_sum_f32(t2);
                     inv = 1.0f / t2;
                 }
 #pragma unroll
                 for (int k = 0; k < NPL; k++)
                     if (lane + 64 * k < A) outp[lane + 64 * k] = sv[k] * inv;
-            }
-            if (lane == 0 && value_out) {
-                float e = d2b[0];
-                for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(sd[pp * D + dd], d2k[dd], e);
-                value_out[pos] = tanhf(e);
             }
         }
         return;
@@ -275,12 +349,15 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
 // The whole network for the PW positions [pos0, pos0+PW) of a batch of n, computed by ONE wave in its
 // own LDS region `wlds` (NetGeom<G,PW>::WAVE_FLOATS floats).  slot_list != nullptr: batch entry i is
 // engine slot slot_list[i] (inputs are read from, and outputs written to, that slot's mailbox).
-template <class G, int PW>
+// WPF: fetch the NEXT layer's weights while the current layer's MFMAs run (36 more VGPRs).  For callers whose weights
+// stream from L2 (a wave pays ~2 k cycles per layer for that round trip otherwise); the persistent Connect4 kernel keeps
+// its weights in LDS and has no registers to spare, so it leaves this off.
+template <class G, int PW, bool WPF = false>
 __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, const int *slot_list, float *wlds,
                                          const typename G::State *states, const int8_t *planes,
                                          const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
                                          float *logits_out, float *policy_out, int pstride, bool zero_lds = true,
-                                         const float *noise_in = nullptr) {
+                                         const float *noise_in = nullptr, WideHead *compact = nullptr) {
     using NG = NetGeom<G, PW>;
     constexpr int W = NG::W, CIN = NG::CIN, A = NG::A, HW = NG::HW, SLOTS = NG::SLOTS, CP = NG::CP,
                   NT = NG::NT, STEPS0 = NG::STEPS0, ACT = NG::ACT, PLANE = NG::PLANE;
@@ -374,17 +451,72 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
     NSTAMP(1);
     // ---- residual tower: 2R convs, K order (tap, r, j) with channel c = 4j + r ---------------------
     const int L = (nd.dbg & 2) ? 0 : 2 * nd.R;
+    f32x4 wnext[WPF ? 9 : 1];
+    f32x4 enext[WPF ? 3 : 1];
+    if constexpr (WPF) {
+        if (L > 0) {
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) wnext[tap] = nd.wt[(size_t)tap * 64 + lane];
+            const float *ep = nd.epi + 48;
+            enext[0] = *(const f32x4 *)(ep + 4 * j);
+            enext[1] = *(const f32x4 *)(ep + 16 + 4 * j);
+            enext[2] = *(const f32x4 *)(ep + 32 + 4 * j);
+        }
+    }
     for (int l = 0; l < L; l++) {
         const float *in = (l & 1) ? actB : actA;
         float *out = (l & 1) ? actA : actB;
         const float *ep = nd.epi + (size_t)(1 + l) * 48;
-        f32x4 bias = *(const f32x4 *)(ep + 4 * j), scale = *(const f32x4 *)(ep + 16 + 4 * j),
-              shift = *(const f32x4 *)(ep + 32 + 4 * j);
+        f32x4 bias, scale, shift;
         f32x4 w[9];
+        if constexpr (WPF) {
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) w[tap] = nd.wt[((size_t)l * 9 + tap) * 64 + lane];
+            for (int tap = 0; tap < 9; tap++) w[tap] = wnext[tap];
+            bias = enext[0];
+            scale = enext[1];
+            shift = enext[2];
+            if (l + 1 < L) { // request layer l + 1 now; the scheduling barrier keeps the requests up here, ahead of this layer's MFMAs
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++) wnext[tap] = nd.wt[((size_t)(l + 1) * 9 + tap) * 64 + lane];
+                enext[0] = *(const f32x4 *)(ep + 48 + 4 * j);
+                enext[1] = *(const f32x4 *)(ep + 48 + 16 + 4 * j);
+                enext[2] = *(const f32x4 *)(ep + 48 + 32 + 4 * j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            bias = *(const f32x4 *)(ep + 4 * j);
+            scale = *(const f32x4 *)(ep + 16 + 4 * j);
+            shift = *(const f32x4 *)(ep + 32 + 4 * j);
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) w[tap] = nd.wt[((size_t)l * 9 + tap) * 64 + lane];
+        }
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = bias;
+        if constexpr (WPF && NT <= 6) {
+            // a lone wave per SIMD (one-wave-per-game kernel, small batches) has nobody to hide its LDS round trips: the
+            // pixel operands of tap + 1 are requested before the MFMAs of tap are issued (the scheduling barrier keeps the
+            // requests there), so that only the first tap of a layer waits for LDS
+            f32x4 b[NT], bn[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) b[t] = *(const f32x4 *)(in + aoff[t] + (-(W + 1) - 1) * 4);
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                if (tap + 1 < 9) {
+                    const int toffn = (((tap + 1) / 3 - 1) * (W + 1) + ((tap + 1) % 3 - 1)) * 4;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) bn[t] = *(const f32x4 *)(in + aoff[t] + toffn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][r], b[t][r], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) b[t] = bn[t];
+            }
+        } else {
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * 4;
@@ -396,6 +528,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
 #pragma unroll
                 for (int t = 0; t < NT; t++)
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][r], b[t][r], acc[t], 0, 0, 0);
+        }
         }
         const bool skip = (l & 1) != 0; // tf.add(batch_norm_2, block input) before the ReLU
 #pragma unroll
@@ -445,8 +578,10 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
             rp[2 * q + 1] = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
         }
     }
+    NSTAMP(3);
     net_head_tail<G, PW>(nd, n, pos0, slot_list, rv, rp, sd, lg, game_id, serial, noise, value_out, logits_out, policy_out,
-                         pstride, noise_in);
+                         pstride, noise_in, compact);
+    NSTAMP(4);
     if constexpr (A > 64) return; // (wide games never ran the scratch restore below)
     NSTAMP(5);
     if (!zero_lds) { // persistent caller: the head scratch overlaid actB's halo slots -- restore the zeros
@@ -466,8 +601,8 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
     const int wave = threadIdx.x >> 6;
     const int pos0 = (blockIdx.x * 4 + wave) * PW;
     if (pos0 >= n) return; // whole wave idle (no block-level sync anywhere)
-    net_body<G, PW>(nd, n, pos0, nullptr, lds + wave * NG::WAVE_FLOATS, states, planes, game_id, serial, noise, value_out,
-                    logits_out, policy_out, pstride);
+    net_body<G, PW, true>(nd, n, pos0, nullptr, lds + wave * NG::WAVE_FLOATS, states, planes, game_id, serial, noise, value_out,
+                          logits_out, policy_out, pstride);
 }
 
 // Compacted batch: *n_ptr leaves were posted this round (slots listed in slot_list).  The grid is always

@@ -11,6 +11,7 @@
 //     over all 4032 actions (NetworkFactory.py:182) cancels in GetPriors' renormalisation
 //     (Blackbird.py:386-387), so the distribution of the priors is the same.
 #pragma once
+#include "net.hip.h"
 #include "tree.hip.h"
 
 struct alignas(128) DCNode {
@@ -48,16 +49,27 @@ struct DCEdges { // per-slot edge pool, stride edge_cap
     float alpha, eps;
 };
 
+// The wave's LDS scratch: the dense float32 image of the masked policy (4032 entries; the values ARE float32 -- the
+// float64 of the reference's `policy * LegalActions` is formed when they are summed) + the compact move list.
 #ifdef BB_STAMPS
-// diagnostic build: cycle stamps accumulate in the wave's LDS scratch (16 words past the 4032-double policy image) and
-// are flushed once when the kernel ends, spread over 64 copies -- atomics inside the timed sections would sit in front
-// of every later s_waitcnt and a thousand waves on one address serialise in L2
-#define DC_LDS_DOUBLES 4048
-#define DST(i, v) do { if (lane == 0) ((unsigned long long *)(lds + 4032))[i] += (unsigned long long)(v); } while (0)
+// diagnostic build: cycle stamps accumulate in the wave's LDS scratch (16 words past the policy image) and are flushed
+// once when the kernel ends, spread over 64 copies -- atomics inside the timed sections would sit in front of every
+// later s_waitcnt and a thousand waves on one address serialise in L2
+#define DC_STAMP_OFF 4768 // past the policy image AND past the network's activations, which share the scratch in mega_dc.hip.h
+#define DC_LDS_FLOATS (DC_STAMP_OFF + 32)
+#define DST(i, v) do { if (lane == 0) ((unsigned long long *)(lds + DC_STAMP_OFF))[i] += (unsigned long long)(v); } while (0)
 #else
-#define DC_LDS_DOUBLES 4032
+#define DC_LDS_FLOATS 4032
 #define DST(i, v) do {} while (0)
 #endif
+
+// What the one-wave-per-game kernel hands from its network phase to its tree phase instead of the evaluator mailbox in
+// global memory (mega_dc.hip.h): the evaluation reduced to five numbers (net.hip.h: WideHead) and the policy-head weights
+// in LDS, from which the expansion computes the probabilities of the legal moves only.
+struct DCHeadLocal {
+    WideHead h;
+    const __attribute__((address_space(3))) float *pdk, *pdb; // policy/policy kernel [2][4032] and bias [4032]
+};
 
 // ---- wave (64 lanes) collectives ----------------------------------------------------------------------
 __device__ __forceinline__ int wave_sum_i(int v) {
@@ -111,26 +123,26 @@ __device__ __forceinline__ void wave_argmax(double &u, int &idx, int &p0, int &p
     }
 }
 
-// numpy pairwise add.reduce over the dense float64 image a[4032] in LDS.  numpy's recursion
+// numpy pairwise add.reduce over the dense image a[4032] in LDS (float32 values, summed as float64).  numpy's recursion
 // (n > 128: n2 = n/2 rounded down to a multiple of 8; pairwise(a, n2) + pairwise(a+n2, n-n2)) cuts 4032
 // into 16 runs of 252 = leaf(120) + (leaf(64) + leaf(68)); a leaf keeps 8 strided partials, folds them
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and adds its tail sequentially.  Lane 3*run+part sums one leaf.
-__device__ __forceinline__ double dc_np_sum(const double *a, int lane) {
+__device__ __forceinline__ double dc_np_sum(const float *a, int lane) {
     double res = 0.0;
     if (lane < 48) {
         int run = lane / 3, part = lane % 3;
         int off = run * 252 + (part == 0 ? 0 : part == 1 ? 120 : 184);
         int len = part == 0 ? 120 : part == 1 ? 64 : 68;
-        const double *b = a + off;
+        const float *b = a + off; // (double)float is exact: the image holds the float32 policy values the reference multiplies by its float64 mask
         double r[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) r[j] = b[j];
+        for (int j = 0; j < 8; j++) r[j] = (double)b[j];
         int i = 8;
         for (; i < len - (len % 8); i += 8)
 #pragma unroll
-            for (int j = 0; j < 8; j++) r[j] += b[i + j];
+            for (int j = 0; j < 8; j++) r[j] += (double)b[i + j];
         res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < len; i++) res += b[i];
+        for (; i < len; i++) res += (double)b[i];
     }
     double nxt = __shfl_down(res, 1, 64);
     double r12 = res + nxt;                      // meaningful on part-1 lanes: leaf(64) + leaf(68)
@@ -147,13 +159,14 @@ __device__ __forceinline__ double dc_np_sum(const double *a, int lane) {
 }
 
 // AddChildren for the node `node` (state st): move generation (lane = from-square), priors, edge rows.
-// policy == nullptr -> MCTS.GetPriors default (ones).  lds: 4032 doubles of scratch owned by this wave.
+// policy == nullptr and hl == nullptr -> MCTS.GetPriors default (ones).  lds: DC_LDS_FLOATS floats of scratch owned by this wave.
 // board_mem: the 64 board bytes of `st` in memory (one coalesced load instead of dynamic indexing into registers)
 // node_idx / node_flags / used: the node's index (== its serial), its flags before the expansion and the slot's edge
 // cursor, loaded by the caller along with its other first-round loads (used is advanced on success).
 __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *node, const DCState &st,
-                          const int8_t *board_mem, const float *policy, uint32_t gid, int lane, double *lds,
-                          int node_idx, int node_flags, int &used) {
+                          const int8_t *board_mem, const float *policy, const DCHeadLocal *hl, uint32_t gid, int lane,
+                          float *lds, int node_idx, int node_flags, int &used) {
+    const bool priors = policy != nullptr || hl != nullptr; // evaluator priors (dense row in memory, or the compact head)
 #ifdef BB_STAMPS
     long long x0 = clock64();
 #endif
@@ -168,7 +181,7 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
     if (off + total > E.edge_cap) return false;
 #ifdef BB_STAMPS
     long long e0 = clock64(), e1 = e0, e2 = e0;
-    if (policy) DST(9, e0 - x0);
+    if (priors) DST(9, e0 - x0);
 #endif
     // The moves are dealt evenly over the lanes (move j of the from-square-major enumeration -> lane j & 63): one
     // policy load, one Beta draw and one edge per lane instead of a serial loop over the busiest square's moves.
@@ -191,18 +204,20 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
     __threadfence_block();
     double tot = 1.0;
     float myp[MPL];
-    if (policy) {
-        for (int i = lane; i < 4032; i += 64) lds[i] = 0.0;
+    if (priors) {
+        for (int i = lane; i < 4032; i += 64) lds[i] = 0.f;
         __threadfence_block();
 #pragma unroll
         for (int i = 0; i < MPL; i++) {
             myp[i] = 0.f;
             if (mya[i] >= 0) {
-                float p = policy[mya[i]];
+                // getPolicy()[a]: from the dense row the network kernel wrote, or computed here from the compact head --
+                // the same operations on the same inputs, so the same bits (net.hip.h: wide_prob)
+                float p = hl ? wide_prob<64>(hl->h, hl->pdk[mya[i]], hl->pdk[4032 + mya[i]], hl->pdb[mya[i]]) : policy[mya[i]];
                 if (E.noise_on)
                     p = (1.0f - E.eps) * p + E.eps * bb_beta_noise(d.seed, gid, (uint32_t)node_idx, (uint32_t)mya[i], E.alpha);
                 myp[i] = p;
-                lds[mya[i]] = (double)p; // float32 * float64 legal mask (1.0)
+                lds[mya[i]] = p; // float32 * float64 legal mask (1.0): widened when summed
             }
         }
 #ifdef BB_STAMPS
@@ -223,7 +238,7 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
             E.e[e].Q = 0.f;
             E.e[e].W = 0.f;
             E.e[e].child = CHILD_NONE;
-            E.e[e].cP = policy ? d.c_puct * __ddiv_rn((double)myp[i], tot) : d.c_puct * 1.0;
+            E.e[e].cP = priors ? d.c_puct * __ddiv_rn((double)myp[i], tot) : d.c_puct * 1.0;
         }
     if (lane == 0) {
         node->flags = node_flags | NODE_EXPANDED;
@@ -235,7 +250,7 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
     }
     used = off + total;
 #ifdef BB_STAMPS
-    if (policy) {
+    if (priors) {
         DST(5, e1 - e0);
         DST(6, e2 - e1);
         DST(7, clock64() - e2);
@@ -245,7 +260,7 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
     return true;
 }
 
-__device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int lane, double *lds) {
+__device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int lane, float *lds, const DCHeadLocal *hl = nullptr) {
     // One wave per game and one wave per SIMD: this step is a chain of dependent HBM round trips (2-3 us each on
     // these sparsely touched pools), so every word that does not depend on another load is requested up front, and
     // the statistics the backup will update are fetched BEFORE the expansion, whose work then hides their latency.
@@ -254,7 +269,7 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
 #endif
     const int leaf = d.pend_leaf[g];
     const int pend_exp = d.pend_expand[g];
-    const float v = d.eval_value[g];
+    const float v = hl ? hl->h.value : d.eval_value[g];
     const int plen = d.path_len[g];
     const int lid = d.game_lid[g];
     const uint32_t *pn = d.path + (size_t)g * DragonChess::MAXPATH;
@@ -298,8 +313,8 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
 #endif
     if (pend_exp) {
         uint32_t gid = d.first_game_id + (uint32_t)lid;
-        if (!dc_expand(d, E, g, node, st, ((const DCState *)d.leaf_state)[g].b, d.eval_policy + (size_t)g * 4032, gid, lane, lds, leaf,
-                       leaf_flags, used) && lane == 0)
+        if (!dc_expand(d, E, g, node, st, ((const DCState *)d.leaf_state)[g].b, hl ? nullptr : d.eval_policy + (size_t)g * 4032, hl, gid,
+                       lane, lds, leaf, leaf_flags, used) && lane == 0)
             d.ctr[(size_t)g * 8 + 6] += 1;
     }
     int player = st.player, prev = st.prev;
@@ -372,7 +387,7 @@ __device__ __forceinline__ int dc_create_child(const TreeDev &d, const DCEdges &
     return word;
 }
 
-__device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int lane, double *lds) {
+__device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int lane, float *lds) {
     const int lid = d.game_lid[g], sims_left = d.sims_left[g];
     int cur = d.root[g];
     int nn = d.n_nodes[g];
@@ -432,7 +447,7 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
             if (!have_st) st = node->st;
             if (flags & NODE_TERMINAL) { term_leaf = 1; break; }
             if (!inline_expand) { expand = 1; break; }
-            if (!dc_expand(d, E, g, node, st, node->st.b, nullptr, 0u, lane, lds, cur, flags, used)) { overflow = 1; break; }
+            if (!dc_expand(d, E, g, node, st, node->st.b, nullptr, nullptr, 0u, lane, lds, cur, flags, used)) { overflow = 1; break; }
             __threadfence_block();
             if (!fixed) break;
             n_edges = node->n_edges;
@@ -539,12 +554,12 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
 }
 
 __global__ void __launch_bounds__(256) k_dc_tree_step(TreeDev d, DCEdges E) {
-    __shared__ double lds_all[4][DC_LDS_DOUBLES];
+    __shared__ __attribute__((aligned(16))) float lds_all[4][DC_LDS_FLOATS];
     int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (g >= d.n_slots) return;
-    double *lds = lds_all[wv];
+    float *lds = lds_all[wv];
 #ifdef BB_STAMPS
-    if (lane < 16) ((unsigned long long *)(lds + 4032))[lane] = 0;
+    if (lane < 16) ((unsigned long long *)(lds + DC_STAMP_OFF))[lane] = 0;
     __threadfence_block();
     long long t0 = clock64();
 #endif
@@ -560,13 +575,13 @@ __global__ void __launch_bounds__(256) k_dc_tree_step(TreeDev d, DCEdges E) {
         DST(0, t1 - t0);
         DST(2, t2 - t1);
         DST(4, 1);
-        for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[(size_t)(g & 63) * 16 + i], ((unsigned long long *)(lds + 4032))[i]);
+        for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[(size_t)(g & 63) * 16 + i], ((unsigned long long *)(lds + DC_STAMP_OFF))[i]);
     }
 #endif
 }
 
 __global__ void __launch_bounds__(256) k_dc_tree_apply(TreeDev d, DCEdges E) {
-    __shared__ double lds[4][DC_LDS_DOUBLES];
+    __shared__ __attribute__((aligned(16))) float lds[4][DC_LDS_FLOATS];
     int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (g >= d.n_slots) return;
     dc_phase_apply(d, E, g, lane, lds[wv]);
@@ -804,8 +819,8 @@ __device__ void dc_write_example(const TreeDev &d, const DCEdges &E, int lid, in
 
 // GenerateTrainingSamples' loop body for one game (one wave): last result applied, move sampled, example written,
 // root advanced, game finished / slot handed to the next game (Blackbird.py:240-268)
-__device__ void dc_selfplay_move_body(const TreeDev &d, const DCEdges &E, int g, int lane, double *lds) {
-    dc_phase_apply(d, E, g, lane, lds);
+__device__ void dc_selfplay_move_body(const TreeDev &d, const DCEdges &E, int g, int lane, float *lds, const DCHeadLocal *hl = nullptr) {
+    dc_phase_apply(d, E, g, lane, lds, hl);
     __threadfence_block();
     int lid = d.game_lid[g];
     if (lid < 0) return;
@@ -867,7 +882,7 @@ __device__ void dc_selfplay_move_body(const TreeDev &d, const DCEdges &E, int g,
 }
 
 __global__ void __launch_bounds__(256) k_dc_selfplay_move(TreeDev d, DCEdges E) {
-    __shared__ double lds[4][DC_LDS_DOUBLES];
+    __shared__ __attribute__((aligned(16))) float lds[4][DC_LDS_FLOATS];
     int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (g >= d.n_slots) return;
     dc_selfplay_move_body(d, E, g, lane, lds[wv]);
