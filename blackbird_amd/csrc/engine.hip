@@ -185,7 +185,6 @@ struct bb_engine {
     TreeDev dev;
     DCEdges edges; // DragonChess only
     int32_t *d_child_action = nullptr;
-    float *d_eval_noise = nullptr;
     NetDev net;
     bool has_weights = false;
     int net_F = 0, net_C = 0;
@@ -259,7 +258,7 @@ static int engine_alloc(bb_engine *e) {
         dalloc(e, d.out_root_winrate, n) || dalloc(e, d.out_child_value, n * G::S) || dalloc(e, e->d_u, n) ||
         dalloc(e, e->d_actions, n) || dalloc(e, d.stamps, 16 * 64) || dalloc(e, d.resume_cur, n) ||
         dalloc(e, d.resume_depth, n) || dalloc(e, d.post_count, 8) || dalloc(e, d.post_slot, n) ||
-        dalloc(e, e->d_eval_noise, n * G::S))
+        false)
         return BB_ERR_HIP;
     typename G::State *ls;
     if (dalloc(e, ls, n)) return BB_ERR_HIP;
@@ -414,7 +413,7 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     d.gpw = 64 / e->info.S;
     d.level_budget = 16; // measured optimum 14-20 on MI355X, Connect4 @800 sims (profiles/README.md)
     d.slot_offset = 0;
-    d.eval_noise = nullptr;
+    d.pool_g0 = 0;
     d.noise_alpha = cfg->alpha;
     d.lid_stride = cfg->n_slots;
     if (const char *env = getenv("BB_LEVEL_BUDGET")) {
@@ -1125,7 +1124,6 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
             bool timed = e->time_every > 0 && e->ev_used + 2 <= e->ev_pool.size();
             if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
             TreeDev dm = d;
-            dm.eval_noise = (e->cfg.noise_on && getenv("BB_TREE_NOISE")) ? e->d_eval_noise : nullptr; // default: network waves draw the noise
             const int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
             k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
             HIPCHK(hipGetLastError());

@@ -244,5 +244,5 @@ __global__ void __launch_bounds__(256) k_gnet_heads(GNetDev gd, NetDev nd, int n
         rp[2 * q + 1] = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
     }
     net_head_tail<G, 1>(nd, n, pos, slot_list, rv, rp, sd, lg, game_id, serial, noise, value_out, logits_out, policy_out,
-                        pstride, nullptr);
+                        pstride);
 }

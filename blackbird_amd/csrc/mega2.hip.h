@@ -34,16 +34,12 @@ __device__ __forceinline__ void release_global_then_lds() {
 
 // ---- per-game control state shadowed in LDS for the lifetime of the launch ----------------------------------
 // async_game touches a dozen per-slot scalars, the evaluator mailbox and the recorded path of a game on every
-// call, each a dependent L2 round trip.  The persistent kernels own their 16 games for the whole launch, so they
-// copy that state into LDS once, point a private TreeDev at the copies (generic pointers, rebased so that index
-// g0 + i lands on entry i) and write everything back before the launch ends.  The node pools stay in HBM.
-// 64-bit generic (flat) address of an LDS object, as an integer the optimiser cannot trace back to LDS
-__device__ __forceinline__ unsigned long long generic_addr(const void *p) {
-    unsigned long long a = (unsigned long long)p;
-    asm volatile("" : "+v"(a));
-    return a;
-}
-
+// call, each a dependent L2 round trip.  The persistent kernel owns its 16 games for the whole launch, so it
+// copies that state into LDS once, points a private TreeDev at the copies and writes everything back before the
+// launch ends.  The tree code indexes these arrays with the workgroup-LOCAL game number (TreeDev::pool_g0 carries the
+// workgroup's first slot for the node pools, which stay in HBM), so the pointers are the plain addresses of __shared__
+// arrays: the compiler sees the LDS address space and emits ds_read / ds_write with immediate offsets from one base
+// register, instead of flat_* instructions through twenty 64-bit generic addresses held in VGPR pairs.
 template <class G, int GW>
 struct GameShadow {
     static constexpr int S = G::S, MP = G::MAXPATH;
@@ -76,14 +72,13 @@ struct GameShadow {
 #undef X
         for (int i = threadIdx.x; i < n; i += nthreads) ((typename G::State *)d.leaf_state)[g0 + i] = leaf_state[i];
     }
-    __device__ __forceinline__ TreeDev rebased(const TreeDev &d, int g0) {
+    __device__ __forceinline__ TreeDev local(const TreeDev &d, int g0) {
         TreeDev r = d;
-        // (integer arithmetic on the generic address: `array - g0` as pointer arithmetic is out of bounds, and the
-        // compiler folds it into 32-bit LDS-offset arithmetic that wraps)
-#define X(f, per) r.f = (decltype(r.f))(generic_addr(f) - (unsigned long long)g0 * (per) * sizeof(f[0]));
+#define X(f, per) r.f = f;
         BB_SHADOW_ARRAYS(X)
 #undef X
-        r.leaf_state = (void *)(generic_addr(leaf_state) - (unsigned long long)g0 * sizeof(leaf_state[0]));
+        r.leaf_state = leaf_state;
+        r.pool_g0 = g0;
         return r;
     }
 };
@@ -155,7 +150,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
     const int g0 = blockIdx.x * GW;
     const int n_mine = dg.n_slots - g0 < GW ? dg.n_slots - g0 : GW;
     shadow.load(dg, g0, n_mine, MEGA2_THREADS);
-    const TreeDev d = shadow.rebased(dg, g0); // everything below works on the LDS copies
+    const TreeDev d = shadow.local(dg, g0); // everything below works on the LDS copies, indexed by the local game number
     if (threadIdx.x == 0) {
         qc.head = 0;
         qc.tail = 0;
@@ -188,7 +183,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
         __builtin_amdgcn_s_setprio(3);
         const int li = (l64 / S) * TREEW + tw, lane = l64 % S; // games are dealt round-robin to the tree waves
         const bool mine = l64 < GPT * S && li < GW && g0 + li < d.n_slots;
-        const int g = g0 + li;
+        const int g = li; // local game number: index of the LDS copies
         int left = mine ? visits : 0;
 #ifdef BB_STAMPS
         long long t_work = 0, t_all0 = clock64(), n_calls = 0, n_lanes = 0, t_pick = 0, n_pick = 0;
@@ -263,10 +258,10 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
             n_evals++;
             t_qwait += wall_clock64() - ts_post[li];
 #endif
-            if (l64 == 0) myslot[wave] = g0 + li;
+            if (l64 == 0) myslot[wave] = li;
 #ifdef Q_HASH
             {
-                int slot = g0 + li;
+                int slot = li;
                 uint64_t sl = d.salt + (d.salt_per_game ? (uint64_t)(d.leaf_game_id[slot] - d.first_game_id) : 0ull);
                 uint64_t z = hash_state<G>(((const typename G::State *)d.leaf_state)[slot], sl);
                 if (l64 == 0) d.eval_value[slot] = bb_hash_value(z);
@@ -274,7 +269,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
             }
 #else
             net_body<G, 1>(ndl, 1, 0, &myslot[wave], wl, (const typename G::State *)d.leaf_state, nullptr, d.leaf_game_id,
-                           d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false, d.eval_noise);
+                           d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false);
 #endif
             release_global_then_lds(); // value / policy before the state word
 #ifdef BB_STAMPS
@@ -297,7 +292,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
     }
     __syncthreads();
     if (qc.abort_flag) { // a wait ran into the wall-clock limit: surfaces as bb_counters.overflow
-        if (threadIdx.x == 0) d.ctr[(size_t)g0 * 8 + 6] += 1;
+        if (threadIdx.x == 0) d.ctr[6] += 1;
         // a leaf that was queued but never evaluated must not be applied by the next launch (its mailbox holds the
         // previous evaluation): drop it, the simulation is redone from the root
         if ((int)threadIdx.x < n_mine && gstate[threadIdx.x] == 1) shadow.pend_leaf[threadIdx.x] = -1;

@@ -37,7 +37,7 @@ __device__ __attribute__((noinline)) void dc_fused_net(const NetDev &nd_, const 
     nl = as_lds(nl);
     hl = as_lds(hl);
     net_body<DragonChess, 1, true>(nd, 1, 0, slot, nl, (const DCState *)d.leaf_state, nullptr, d.leaf_game_id, d.leaf_serial, 0,
-                             nullptr, nullptr, nullptr, DragonChess::A, true, nullptr, &hl->h);
+                             nullptr, nullptr, nullptr, DragonChess::A, true, &hl->h);
     __threadfence_block();
 }
 __device__ __attribute__((noinline)) void dc_fused_move(const TreeDev &d_, const DCEdges &E_, int g, int lane, float *tl, const DCHeadLocal *hl) {

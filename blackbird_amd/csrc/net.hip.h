@@ -144,8 +144,7 @@ template <class G, int PW>
 __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0, const int *slot_list, const float *rv,
                                               const float *rp, float *sd, float *lg, const uint32_t *game_id,
                                               const int32_t *serial, int noise, float *value_out, float *logits_out,
-                                              float *policy_out, int pstride, const float *noise_in,
-                                              WideHead *compact = nullptr) {
+                                              float *policy_out, int pstride, WideHead *compact = nullptr) {
     using NG = NetGeom<G, PW>;
     constexpr int A = NG::A, HW = NG::HW;
     const int lane = threadIdx.x & 63;
@@ -265,7 +264,6 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
             int pos = live ? OI(pos0 + q / A) : 0;
             uint32_t gid = game_id ? game_id[pos] : (uint32_t)noise, ser = serial ? (uint32_t)serial[pos] : (uint32_t)pos;
             float r = (nd.dbg & 8) ? nd.alpha : -1.0f;
-            if (noise_in && live) r = noise_in[(size_t)pos * pstride + a]; // drawn by the tree wave that posted the leaf
             for (uint32_t k = 0; k < 32 && __any(live && r < 0.0f); k += 2) {
                 float mine = (live && r < 0.0f) ? bb_beta_pair(nd.seed, gid, ser, (uint32_t)a, ia, ib, k + sub) : -1.0f;
                 float other = __shfl_xor(mine, 1, 64);
@@ -357,7 +355,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
                                          const typename G::State *states, const int8_t *planes,
                                          const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
                                          float *logits_out, float *policy_out, int pstride, bool zero_lds = true,
-                                         const float *noise_in = nullptr, WideHead *compact = nullptr) {
+                                         WideHead *compact = nullptr) {
     using NG = NetGeom<G, PW>;
     constexpr int W = NG::W, CIN = NG::CIN, A = NG::A, HW = NG::HW, SLOTS = NG::SLOTS, CP = NG::CP,
                   NT = NG::NT, STEPS0 = NG::STEPS0, ACT = NG::ACT, PLANE = NG::PLANE;
@@ -580,7 +578,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
     }
     NSTAMP(3);
     net_head_tail<G, PW>(nd, n, pos0, slot_list, rv, rp, sd, lg, game_id, serial, noise, value_out, logits_out, policy_out,
-                         pstride, noise_in, compact);
+                         pstride, compact);
     NSTAMP(4);
     if constexpr (A > 64) return; // (wide games never ran the scratch restore below)
     NSTAMP(5);

@@ -109,7 +109,10 @@ struct TreeDev {
     // a TreeDev may be a VIEW of a slot range (pointers pre-offset): pipelined self-play runs two views on two streams
     int slot_offset;                    // first slot of this view in the engine
     int lid_stride;                     // engine-wide slot count: a slot's next game id is lid + lid_stride
-    float *eval_noise;                  // [n_slots][S] prior noise drawn at posting time (persistent kernel), or nullptr
+    // The persistent kernel keeps its workgroup's per-slot arrays (everything above except the node pool) in LDS and
+    // indexes them with the LOCAL slot number; the node pool stays in HBM and is indexed with pool_g0 + local number.
+    // Everywhere else pool_g0 is 0 and the slot number is the engine's.
+    int pool_g0;
     float noise_alpha;
     unsigned long long *stamps; // diagnostic build only (BB_STAMPS): [apply, fence, select, levels, waves]
 };
@@ -241,7 +244,7 @@ __device__ void phase_apply(const TreeDev &d, int g, int lane) {
     constexpr int S = G::S, A = G::A;
     int leaf = d.pend_leaf[g];
     if (leaf < 0) return;
-    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    Node *pool = (Node *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     Node *node = pool + leaf;
     typename G::State st = ((const typename G::State *)d.leaf_state)[g]; // posted by phase_select
     float v = d.eval_value[g];
@@ -332,7 +335,7 @@ __device__ void phase_select(const TreeDev &d, int g, int lane) {
     using Node = DenseNode<G>;
     constexpr int S = G::S, A = G::A;
     if (d.game_lid[g] < 0 || d.sims_left[g] <= 0) return;
-    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    Node *pool = (Node *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     uint32_t *path = d.path + (size_t)g * G::MAXPATH;
     int cur = d.root[g];
     int nn = d.n_nodes[g];
@@ -487,7 +490,7 @@ __device__ int choose_move(const TreeDev &d, int g, int lane, double temp, doubl
                            float &Wi_out) {
     using Node = DenseNode<G>;
     constexpr int S = G::S, A = G::A;
-    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    Node *pool = (Node *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     Node *node = pool + d.root[g];
     if (!(node->flags & NODE_EXPANDED)) {
         total = 0;
@@ -566,7 +569,7 @@ __global__ void __launch_bounds__(256) k_sample(TreeDev d, double temp) {
 template <class G>
 __device__ void advance_root(const TreeDev &d, int g, int lane, int a, typename G::State &new_st) {
     using Node = DenseNode<G>;
-    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    Node *pool = (Node *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     Node *node = pool + d.root[g];
     typename G::State st = node->st;
     if (!(node->flags & NODE_EXPANDED)) { // `Root.Children is None` -> Root = None; re-prime with the new state
@@ -630,7 +633,7 @@ __global__ void __launch_bounds__(256) k_move_roots(TreeDev d, const int32_t *ac
 template <class G>
 __device__ __forceinline__ void reset_slot(const TreeDev &d, int g, int lid, const typename G::State &st) {
     using Node = DenseNode<G>;
-    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    Node *pool = (Node *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     pool->st = st;
     pool->flags = gs_player(st) << 4;
     pool->legal_mask = 0;
@@ -671,7 +674,7 @@ template <class G>
 __global__ void __launch_bounds__(256) k_get_roots(TreeDev d, typename G::State *out) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.n_slots) return;
-    out[g] = ((DenseNode<G> *)d.nodes + (size_t)g * d.node_cap + d.root[g])->st;
+    out[g] = ((DenseNode<G> *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap + d.root[g])->st;
 }
 
 // ---- self-play: begin / one move for every slot --------------------------------------------------
@@ -719,7 +722,7 @@ __device__ BB_MOVE_BODY_ATTR void selfplay_move_body(const TreeDev &d, int g, in
     constexpr int S = G::S;
     int lid = d.game_lid[g];
     if (lid < 0) return;
-    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    Node *pool = (Node *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     typename G::State st = pool[d.root[g]].st;
     uint32_t gid = d.first_game_id + (uint32_t)lid;
     int ply = d.ply[g];
@@ -802,7 +805,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
     using Node = DenseNode<G>;
     constexpr int S = G::S, A = G::A;
     if (d.game_lid[g] < 0) return false;
-    Node *pool = (Node *)d.nodes + (size_t)g * d.node_cap;
+    Node *pool = (Node *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
 #ifdef BB_STAMPS_DEEP
     long long sa0 = clock64(), s_apply = 0, s_level = 0, s_backup = 0, s_move = 0;
 #endif
@@ -939,9 +942,6 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
             if (lane == 0) d.sim_serial[g] += 1;
             continue;
         }
-        if (d.eval_noise && (fl & F_EXPAND) && lane < A) // Beta(alpha,1-alpha) prior noise for this expansion, one action per lane
-            d.eval_noise[(size_t)g * S + lane] =
-                bb_beta_noise(d.seed, d.first_game_id + (uint32_t)d.game_lid[g], (uint32_t)cur, (uint32_t)lane, d.noise_alpha);
         if (lane == 0) {             // post the leaf for the evaluator
             ((typename G::State *)d.leaf_state)[g] = st;
             d.leaf_game_id[g] = d.first_game_id + (uint32_t)d.game_lid[g];
