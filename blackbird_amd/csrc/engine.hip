@@ -726,6 +726,8 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     nd.seed = e->cfg.seed;
     nd.alpha = e->cfg.alpha;
     nd.eps = e->cfg.epsilon;
+    nd.inv_alpha = 1.0f / nd.alpha;
+    nd.inv_beta = 1.0f / (1.0f - nd.alpha);
     nd.dbg = getenv("BB_NET_DBG") ? atoi(getenv("BB_NET_DBG")) : 0; // ablation switches (timing experiments only; results are wrong when set)
     e->has_weights = true;
     e->net_F = F;

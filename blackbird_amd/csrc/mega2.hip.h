@@ -22,6 +22,9 @@
 
 #define MEGA2_THREADS 768 // 12 waves: NETW network waves + (12 - NETW) tree waves
 #define MEGA2_QCAP 32
+#ifndef BB_QUEUE_WMODE
+#define BB_QUEUE_WMODE 2 // net.hip.h conv_layer: weights in LDS, next tap's operands requested ahead of this tap's MFMAs
+#endif
 
 __device__ __forceinline__ int lds_load(volatile int *p) { return *p; }
 // Release for a flag that lives in LDS while the data lives in global memory: the workgroup-scope fence
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
                 if (l64 < G::A) d.eval_policy[(size_t)slot * S + l64] = bb_hash_policy(z, l64);
             }
 #else
-            net_body<G, 1>(ndl, 1, 0, &myslot[wave], wl, (const typename G::State *)d.leaf_state, nullptr, d.leaf_game_id,
+            net_body<G, 1, BB_QUEUE_WMODE>(ndl, 1, 0, &myslot[wave], wl, (const typename G::State *)d.leaf_state, nullptr, d.leaf_game_id,
                            d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false);
 #endif
             release_global_then_lds(); // value / policy before the state word

@@ -36,7 +36,7 @@ __device__ __attribute__((noinline)) void dc_fused_net(const NetDev &nd_, const 
     slot = as_lds(slot);
     nl = as_lds(nl);
     hl = as_lds(hl);
-    net_body<DragonChess, 1, true>(nd, 1, 0, slot, nl, (const DCState *)d.leaf_state, nullptr, d.leaf_game_id, d.leaf_serial, 0,
+    net_body<DragonChess, 1, 1>(nd, 1, 0, slot, nl, (const DCState *)d.leaf_state, nullptr, d.leaf_game_id, d.leaf_serial, 0,
                              nullptr, nullptr, nullptr, DragonChess::A, true, &hl->h);
     __threadfence_block();
 }

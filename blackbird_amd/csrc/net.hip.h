@@ -20,10 +20,21 @@
 //  * layer weights (9.2 KB each) stream from L2 into 36 VGPRs per layer, pre-swizzled on the host
 //    into the lane order the MFMA A-operand wants.
 #pragma once
+#include <type_traits>
 #include "games.hip.h"
 #include "rng.hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef BB_FUSED_WMODE
+#define BB_FUSED_WMODE 1 // k_net_fused16: weights stream from L2 (net_body WMODE)
+#endif
+
+// Lanes of a wave hand data to each other through LDS (a layer's output pixels are the next layer's neighbours).  The
+// hardware runs a wave's LDS operations in order, but the COMPILER orders memory operations per lane: a store to
+// out[x + c1] and a later load of out[x + c2] differ by a constant for "this lane", so it may hoist the load above the
+// store -- although another lane's store feeds it.  This fence (wavefront scope: no instruction, only an ordering
+// constraint) marks every such hand-over.
+__device__ __forceinline__ void wave_lds_handover() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 struct NetDev {
     int R, D, A;             // blocks, value dense width, actions
@@ -35,6 +46,7 @@ struct NetDev {
     int off_vk, off_v3, off_d1k, off_d1b, off_d2k, off_d2b, off_pk, off_p6, off_pdk, off_pdb;
     uint64_t seed;
     float alpha, eps;
+    float inv_alpha, inv_beta; // 1 / alpha and 1 / (1 - alpha) (float32 quotients, formed once on the host)
     int dbg; // ablation switches for bb_timing_net (0 in production): 1 no heads, 2 no tower, 4 no first conv
 };
 
@@ -154,12 +166,13 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
         const int D = nd.D;
         const float *d1k = hp + nd.off_d1k, *d1b = hp + nd.off_d1b;
         for (int q = lane; q < PW * D; q += 64) { // dense_1 per pixel, then reduce_sum over H,W, ReLU
-            int pp = q / D, dd = q % D;
+            int pp = PW == 1 ? 0 : q / D, dd = PW == 1 ? q : q % D;
             float s = 0.f, wk = d1k[dd], wb = d1b[dd];
 #pragma unroll
             for (int p = 0; p < HW; p++) s += __builtin_fmaf(rv[pp * HW + p], wk, wb);
             sd[q] = fmaxf(s, 0.f);
         }
+        wave_lds_handover();
         if constexpr (A <= 64) {
             const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
             for (int q = lane; q < PW * A; q += 64) { // policy dense on the last axis, reduce_sum over H,W
@@ -170,6 +183,7 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
                     s += __builtin_fmaf(rp[2 * (pp * HW + p) + 1], k1, __builtin_fmaf(rp[2 * (pp * HW + p)], k0, kb));
                 lg[q] = s;
             }
+            wave_lds_handover();
         }
     }
 #ifdef BB_STAMPS_NET
@@ -256,7 +270,7 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
     if constexpr (A <= 64) {
     float *nz = lg + PW * A; // [PW][A] Beta(alpha, 1-alpha) draws, one lane per (position, action)
     if (noise) { // two lanes per (position, action): lane pair (2i, 2i+1) tries Philox pairs k and k+1 side by side
-        const float ia = 1.0f / nd.alpha, ib = 1.0f / (1.0f - nd.alpha);
+        const float ia = nd.inv_alpha, ib = nd.inv_beta;
         for (int base = 0; base < PW * A; base += 32) {
             int q = base + (lane >> 1), sub = lane & 1;
             bool live = q < PW * A && pos0 + q / A < n;
@@ -272,6 +286,7 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
             }
             if (live && sub == 0) nz[q] = r >= 0.0f ? r : nd.alpha;
         }
+        wave_lds_handover();
     }
     if constexpr (PW == 1) {
         // one position per wave (work-queue kernel, small batches): lane a finishes action a, so the softmax costs one
@@ -347,10 +362,9 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
 // The whole network for the PW positions [pos0, pos0+PW) of a batch of n, computed by ONE wave in its
 // own LDS region `wlds` (NetGeom<G,PW>::WAVE_FLOATS floats).  slot_list != nullptr: batch entry i is
 // engine slot slot_list[i] (inputs are read from, and outputs written to, that slot's mailbox).
-// WPF: fetch the NEXT layer's weights while the current layer's MFMAs run (36 more VGPRs).  For callers whose weights
-// stream from L2 (a wave pays ~2 k cycles per layer for that round trip otherwise); the persistent Connect4 kernel keeps
-// its weights in LDS and has no registers to spare, so it leaves this off.
-template <class G, int PW, bool WPF = false>
+// WMODE: how the tower's operands reach the MFMAs (see conv_layer below): 0 plain, 1 weights from L2 with next-layer
+// prefetch, 2 weights in LDS with next-tap prefetch.
+template <class G, int PW, int WMODE = 0>
 __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, const int *slot_list, float *wlds,
                                          const typename G::State *states, const int8_t *planes,
                                          const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
@@ -386,7 +400,9 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
     }
     // the PW boards go through LDS so that every lane can decode any cell of any position
     typename G::State *sst = (typename G::State *)(inp + PW * SLOTS * CP);
+    wave_lds_handover(); // (the zero fill above and the data written below touch the same words from different lanes)
     if (!planes && lane < PW) sst[lane] = my_state;
+    wave_lds_handover();
     // ---- input planes -> inp[pos][slot][CP] ---------------------------------------------------
     for (int q = lane; q < PW * HW; q += 64) {
         int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
@@ -405,19 +421,24 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
         }
     }
     // ---- per-tile addressing: lane (j, nn) <-> pixel nn of the tile, channels 4j..4j+3 ---------
-    int aoff[NT];   // float offset of (channel group j, pos, slot) inside an activation buffer
-    int ioff[NT];   // float offset of (pos, slot) inside inp
-    bool valid[NT];
+    // The lanes past the last pixel (42 pixels occupy 48 MFMA columns) work on the LAST pixel once more: they compute
+    // and store the values its own lane stores, to the same addresses, so nothing below needs a lane mask.
+    // Offsets are biased by the most negative tap displacement: every tap of the 3x3 window is then a non-negative
+    // IMMEDIATE offset of the ds_read (no address arithmetic per operand read), and the tile's own pixel sits at +CTR.
+    constexpr int TAP0 = (W + 1) + 1;            // slots between the window's top-left tap and its centre
+    constexpr int CTR = TAP0 * 4;                // ... in floats of an activation plane
+    int aoffb[NT];  // float offset of (channel group j, pos, slot - TAP0) inside an activation buffer
+    int ioffb[NT];  // float offset of (pos, slot - TAP0) inside inp
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         int q = t * 16 + nn;
-        valid[t] = q < PW * HW;
-        int qq = valid[t] ? q : 0;
+        int qq = q < PW * HW ? q : PW * HW - 1;
         int pp = qq / HW, cell = qq % HW, y = cell / W, x = cell % W;
-        int slot = valid[t] ? (y + 1) * (W + 1) + (x + 1) : 0; // invalid lanes read the (zero) corner halo
-        aoff[t] = j * PLANE + (pp * SLOTS + slot) * 4;
-        ioff[t] = (pp * SLOTS + slot) * CP;
+        int slot = (y + 1) * (W + 1) + (x + 1);
+        aoffb[t] = j * PLANE + (pp * SLOTS + slot - TAP0) * 4;
+        ioffb[t] = (pp * SLOTS + slot - TAP0) * CP;
     }
+    wave_lds_handover(); // input planes (and the staged boards) written above are read by other lanes below
     NSTAMP(0);
     f32x4 acc[NT];
     // ---- first conv: K = 9*CIN in natural (tap, c) order, 4 k per MFMA ---------------------------
@@ -430,11 +451,11 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
             int k = 4 * s + j;
             int kk = k < 9 * CIN ? k : 9 * CIN - 1; // padded k: weight is 0, any readable address will do
             int tap = kk / CIN, c = kk % CIN;
-            int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * CP + c;
+            int toff = ((tap / 3) * (W + 1) + (tap % 3)) * CP + c;
             float a = w0r[s];
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                float b = inp[ioff[t] + toff];
+                float b = inp[ioffb[t] + toff];
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
             }
         }
@@ -443,15 +464,24 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
             f32x4 y;
 #pragma unroll
             for (int r = 0; r < 4; r++) y[r] = fmaxf(__builtin_fmaf(acc[t][r], scale[r], shift[r]), 0.f);
-            if (valid[t]) *(f32x4 *)(actA + aoff[t]) = y;
+            *(f32x4 *)(actA + aoffb[t] + CTR) = y;
         }
     }
+    wave_lds_handover();
     NSTAMP(1);
     // ---- residual tower: 2R convs, K order (tap, r, j) with channel c = 4j + r ---------------------
-    const int L = (nd.dbg & 2) ? 0 : 2 * nd.R;
-    f32x4 wnext[WPF ? 9 : 1];
-    f32x4 enext[WPF ? 3 : 1];
-    if constexpr (WPF) {
+    // One layer = 9 taps x 4 k-steps x NT tiles of MFMAs + the epilogue; written once (conv_layer) and instantiated for
+    // the first conv of a block (actA -> actB) and the second (actB -> actA, + the block's input before the ReLU), so
+    // that buffers and the skip connection are compile-time facts of each copy.  How the operands arrive (WMODE):
+    //   0  read where they are used (batch kernels: other waves of the SIMD cover the latency)
+    //   1  weights stream from L2: the NEXT layer's 9 weight vectors are requested while this layer's MFMAs run
+    //      (36 more VGPRs); with few tiles the pixel operands of tap + 1 are requested ahead of tap's MFMAs as well
+    //   2  weights in LDS (persistent kernel): weight vector and pixel operands of tap + 1 are requested ahead of tap's MFMAs
+    const int R_eff = (nd.dbg & 2) ? 0 : nd.R;
+    const int L = 2 * R_eff;
+    f32x4 wnext[WMODE == 1 ? 9 : 1];
+    f32x4 enext[WMODE == 1 ? 3 : 1];
+    if constexpr (WMODE == 1) {
         if (L > 0) {
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) wnext[tap] = nd.wt[(size_t)tap * 64 + lane];
@@ -461,13 +491,12 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
             enext[2] = *(const f32x4 *)(ep + 32 + 4 * j);
         }
     }
-    for (int l = 0; l < L; l++) {
-        const float *in = (l & 1) ? actB : actA;
-        float *out = (l & 1) ? actA : actB;
+    auto conv_layer = [&](const int l, const float *in, float *out, auto skip_tag) __attribute__((always_inline)) {
+        constexpr bool SKIP = decltype(skip_tag)::value; // tf.add(batch_norm_2, block input) before the ReLU
         const float *ep = nd.epi + (size_t)(1 + l) * 48;
         f32x4 bias, scale, shift;
-        f32x4 w[9];
-        if constexpr (WPF) {
+        if constexpr (WMODE == 1) {
+            f32x4 w[9];
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) w[tap] = wnext[tap];
             bias = enext[0];
@@ -481,67 +510,110 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
                 enext[2] = *(const f32x4 *)(ep + 48 + 32 + 4 * j);
             }
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = bias;
+            if constexpr (NT <= 6) {
+                // a lone wave per SIMD (one-wave-per-game kernel, small batches) has nobody to hide its LDS round trips
+                f32x4 b[NT], bn[NT];
+#pragma unroll
+                for (int t = 0; t < NT; t++) b[t] = *(const f32x4 *)(in + aoffb[t]);
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++) {
+                    if (tap + 1 < 9) {
+                        const int toffn = (((tap + 1) / 3) * (W + 1) + ((tap + 1) % 3)) * 4;
+#pragma unroll
+                        for (int t = 0; t < NT; t++) bn[t] = *(const f32x4 *)(in + aoffb[t] + toffn);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][r], b[t][r], acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < NT; t++) b[t] = bn[t];
+                }
+            } else {
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++) {
+                    const int toff = ((tap / 3) * (W + 1) + (tap % 3)) * 4;
+                    f32x4 b[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; t++) b[t] = *(const f32x4 *)(in + aoffb[t] + toff);
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][r], b[t][r], acc[t], 0, 0, 0);
+                }
+            }
         } else {
             bias = *(const f32x4 *)(ep + 4 * j);
             scale = *(const f32x4 *)(ep + 16 + 4 * j);
             shift = *(const f32x4 *)(ep + 32 + 4 * j);
 #pragma unroll
-            for (int tap = 0; tap < 9; tap++) w[tap] = nd.wt[((size_t)l * 9 + tap) * 64 + lane];
-        }
+            for (int t = 0; t < NT; t++) acc[t] = bias;
+            if constexpr (WMODE == 2) {
+                f32x4 b[NT], bn[NT], wc, wn;
+                wc = nd.wt[((size_t)l * 9) * 64 + lane];
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = bias;
-        if constexpr (WPF && NT <= 6) {
-            // a lone wave per SIMD (one-wave-per-game kernel, small batches) has nobody to hide its LDS round trips: the
-            // pixel operands of tap + 1 are requested before the MFMAs of tap are issued (the scheduling barrier keeps the
-            // requests there), so that only the first tap of a layer waits for LDS
-            f32x4 b[NT], bn[NT];
+                for (int t = 0; t < NT; t++) b[t] = *(const f32x4 *)(in + aoffb[t]);
 #pragma unroll
-            for (int t = 0; t < NT; t++) b[t] = *(const f32x4 *)(in + aoff[t] + (-(W + 1) - 1) * 4);
+                for (int tap = 0; tap < 9; tap++) {
+                    if (tap + 1 < 9) {
+                        const int toffn = (((tap + 1) / 3) * (W + 1) + ((tap + 1) % 3)) * 4;
+                        wn = nd.wt[((size_t)l * 9 + tap + 1) * 64 + lane];
 #pragma unroll
-            for (int tap = 0; tap < 9; tap++) {
-                if (tap + 1 < 9) {
-                    const int toffn = (((tap + 1) / 3 - 1) * (W + 1) + ((tap + 1) % 3 - 1)) * 4;
+                        for (int t = 0; t < NT; t++) bn[t] = *(const f32x4 *)(in + aoffb[t] + toffn);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int t = 0; t < NT; t++) bn[t] = *(const f32x4 *)(in + aoff[t] + toffn);
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[r], b[t][r], acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wc = wn;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) b[t] = bn[t];
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                f32x4 w[9];
 #pragma unroll
-                for (int r = 0; r < 4; r++)
+                for (int tap = 0; tap < 9; tap++) w[tap] = nd.wt[((size_t)l * 9 + tap) * 64 + lane];
 #pragma unroll
-                    for (int t = 0; t < NT; t++)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][r], b[t][r], acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int tap = 0; tap < 9; tap++) {
+                    const int toff = ((tap / 3) * (W + 1) + (tap % 3)) * 4;
+                    f32x4 b[NT];
 #pragma unroll
-                for (int t = 0; t < NT; t++) b[t] = bn[t];
+                    for (int t = 0; t < NT; t++) b[t] = *(const f32x4 *)(in + aoffb[t] + toff);
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][r], b[t][r], acc[t], 0, 0, 0);
+                }
             }
-        } else {
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int toff = ((tap / 3 - 1) * (W + 1) + (tap % 3 - 1)) * 4;
-            f32x4 b[NT];
-#pragma unroll
-            for (int t = 0; t < NT; t++) b[t] = *(const f32x4 *)(in + aoff[t] + toff);
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-#pragma unroll
-                for (int t = 0; t < NT; t++)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][r], b[t][r], acc[t], 0, 0, 0);
         }
-        }
-        const bool skip = (l & 1) != 0; // tf.add(batch_norm_2, block input) before the ReLU
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             f32x4 y;
             f32x4 sk = {0.f, 0.f, 0.f, 0.f};
-            if (skip) sk = *(const f32x4 *)(out + aoff[t]);
+            if constexpr (SKIP) sk = *(const f32x4 *)(out + aoffb[t] + CTR);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 float v = __builtin_fmaf(acc[t][r], scale[r], shift[r]);
-                if (skip) v = v + sk[r];
+                if constexpr (SKIP) v = v + sk[r];
                 y[r] = fmaxf(v, 0.f);
             }
-            if (valid[t]) *(f32x4 *)(out + aoff[t]) = y;
+            *(f32x4 *)(out + aoffb[t] + CTR) = y;
         }
+        wave_lds_handover(); // this layer's pixels are the next layer's (and the heads') operands, across lanes
+    };
+    for (int blk = 0; blk < R_eff; blk++) {
+        conv_layer(2 * blk, actA, actB, std::false_type{});
+        conv_layer(2 * blk + 1, actB, actA, std::true_type{});
     }
     if (nd.dbg & 1) {
         if (value_out && lane == 0) value_out[OI(pos0)] = acc[0][0];
@@ -576,6 +648,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
             rp[2 * q + 1] = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
         }
     }
+    wave_lds_handover();
     NSTAMP(3);
     net_head_tail<G, PW>(nd, n, pos0, slot_list, rv, rp, sd, lg, game_id, serial, noise, value_out, logits_out, policy_out,
                          pstride, compact);
@@ -584,7 +657,9 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
     NSTAMP(5);
     if (!zero_lds) { // persistent caller: the head scratch overlaid actB's halo slots -- restore the zeros
         const int used = 3 * PW * HW + PW * nd.D + 2 * PW * (A <= 64 ? A : 0);
+        wave_lds_handover();
         for (int i = lane; i < used; i += 64) actB[i] = 0.f;
+        wave_lds_handover();
     }
 }
 
@@ -599,7 +674,7 @@ k_net_fused16(NetDev nd, int n, const typename G::State *states, const int8_t *p
     const int wave = threadIdx.x >> 6;
     const int pos0 = (blockIdx.x * 4 + wave) * PW;
     if (pos0 >= n) return; // whole wave idle (no block-level sync anywhere)
-    net_body<G, PW, true>(nd, n, pos0, nullptr, lds + wave * NG::WAVE_FLOATS, states, planes, game_id, serial, noise, value_out,
+    net_body<G, PW, BB_FUSED_WMODE>(nd, n, pos0, nullptr, lds + wave * NG::WAVE_FLOATS, states, planes, game_id, serial, noise, value_out,
                           logits_out, policy_out, pstride);
 }
 
