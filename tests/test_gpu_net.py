@@ -168,3 +168,26 @@ def test_empty_and_single_position_batches():
     v2, l2, p2 = eng.net_eval(states=st[:1500])  # 2 per wave
     assert np.array_equal(v2, v[:1500]) and np.array_equal(l2, l[:1500]) and np.array_equal(p2, p[:1500])
     eng.close()
+
+
+@pytest.mark.parametrize("game,og", [(_lib.GAME_CONNECT4, 0), (_lib.GAME_TICTACTOE, 1)])
+def test_every_positions_per_wave_variant_matches_oracle(orc, game, og):
+    """The fused kernel is instantiated for 1, 2 and the LDS-filling number of positions per wave (12 for TicTacToe, 4 for
+    Connect4), picked by batch size; the tile counts (1, 2, 7 / 3, 6, 11 tiles of 16 pixels) go through different operand
+    schedules.  All of them against the oracle, logits bit-identical.  (Round 2 found a compiler reordering across the
+    cross-lane LDS hand-over between layers that only struck the one-tile variant: net.hip.h wave_lds_handover.)"""
+    gi = _lib.game_info(game)
+    flat = W.flatten(W.init_weights(gi.C, 16, 4, 16, gi.A, seed=2, perturb=True))
+    eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)
+    eng.load_weights(flat)
+    rng = np.random.RandomState(1)
+    b, pl = boards_for(game, rng, 3000)
+    st = _lib.pack_grid(game, b, pl)
+    planes = _lib.game_encode(game, st)
+    ov, ol, op = orc.net_forward(orc.NetWeights(gi.H, gi.W, gi.C, 16, 4, 16, gi.A, flat), planes[:300])
+    for cnt in (3000, 1500, 300, 1):
+        v, l, p = eng.net_eval(states=st[:cnt])
+        k = min(cnt, 300)
+        assert np.array_equal(l[:k], ol[:k]), (cnt, float(np.abs(l[:k] - ol[:k]).max()))
+        assert np.max(np.abs(v[:k] - ov[:k])) <= TOL and np.max(np.abs(p[:k] - op[:k])) <= TOL
+    eng.close()
