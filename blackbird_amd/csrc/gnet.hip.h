@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256) k_gnet_heads(GNetDev gd, NetDev nd, int n
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pos = blockIdx.x * 4 + wave;
     if (pos >= n) return;
-    float *rv = scratch[wave], *rp = rv + HW, *sd = rp + 2 * HW, *lg = sd + nd.D;
+    float *rv = scratch[wave], *rp = rv + HW;
     const float *hp = nd.head;
     const float *vk = hp + nd.off_vk, *v3 = hp + nd.off_v3, *pk = hp + nd.off_pk, *p6 = hp + nd.off_p6;
     const float *ap = act + (size_t)pos * gd.NCB * 4 * PLANE;
@@ -243,6 +243,6 @@ __global__ void __launch_bounds__(256) k_gnet_heads(GNetDev gd, NetDev nd, int n
         rp[2 * q] = fmaxf(__builtin_fmaf(a0, p6[2], p6[4]), 0.f);
         rp[2 * q + 1] = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
     }
-    net_head_tail<G, 1>(nd, n, pos, slot_list, rv, rp, sd, lg, game_id, serial, noise, value_out, logits_out, policy_out,
-                        pstride);
+    wave_lds_handover();
+    net_head_tail<G, 1>(nd, n, pos, slot_list, rv, rp, game_id, serial, noise, value_out, logits_out, policy_out, pstride);
 }

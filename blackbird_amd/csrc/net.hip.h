@@ -148,214 +148,158 @@ __device__ __forceinline__ void wide_head_stats(WideHead &h, PK pdk, PK pdb, int
     h.inv = 1.0f / tot;
 }
 
-// Everything after the two 1x1 head convolutions, shared by the fused F=16 kernels and the general-F path
-// (gnet.hip.h): rv / rp hold relu(bn(conv)) per pixel of the PW positions, sd / lg are scratch.
-// NetworkFactory.py:100-183: dense_1 per pixel -> reduce_sum -> ReLU -> dense_2 -> tanh;  policy dense on the
-// last axis -> reduce_sum -> softmax (-> Dirichlet mix).
-template <class G, int PW>
-__device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0, const int *slot_list, const float *rv,
-                                              const float *rp, float *sd, float *lg, const uint32_t *game_id,
-                                              const int32_t *serial, int noise, float *value_out, float *logits_out,
-                                              float *policy_out, int pstride, WideHead *compact = nullptr) {
-    using NG = NetGeom<G, PW>;
-    constexpr int A = NG::A, HW = NG::HW;
+// ---- heads after the two 1x1 convolutions (NetworkFactory.py:105-183) -------------------------------------------------
+// The reference applies `dense` to the last axis of the [H, W, c] head activations and then reduce_sums over H and W:
+//     value:  relu(sum_p (r[p] * k[d] + b[d]))        policy logits:  sum_p (r0[p] * k0[a] + r1[p] * k1[a] + b[a])
+// which is a global sum pool followed by a tiny dense layer:
+//     relu(k[d] * R + HW * b[d]),                       k0[a] * R0 + k1[a] * R1 + HW * b[a],     R* = sum_p r*[p].
+// This file computes the pooled form: three wave reductions and one fma per unit instead of H*W dependent fma/add
+// steps per unit (460 of the ~1400 vector instructions of a Connect4 evaluation).  TensorFlow does not define the
+// order of a reduce_sum, so neither form is "the" rounding; they agree to ~1e-7 relative (tests/test_oracle_net.py
+// holds both against each other and against PyTorch) and the oracle's orc_net_forward restates THIS form -- sums as the
+// fixed pairwise tree below -- so that GPU and oracle logits stay bit-identical.
+//
+// reduce_sum over H, W of one position: pixel p on lane p (lanes >= H*W hold 0.0), xor butterfly with strides 32 ... 1.
+// Every lane ends with the same bits; the tree does not depend on how positions are packed into waves.
+__device__ __forceinline__ float pooled_sum(float v) { return wave_sum_f32(v); }
+
+// One position's value / policy from its pooled activations (R, R0, R1 are wave-uniform); all 64 lanes take part.
+// `live` = the position exists (pos < n); outputs go to index `pos`.
+template <class G>
+__device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, float R1, int pos, bool live,
+                                         const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
+                                         float *logits_out, float *policy_out, int pstride, WideHead *compact) {
+    constexpr int A = G::A, HW = G::H * G::W;
     const int lane = threadIdx.x & 63;
     const float *hp = nd.head;
-    auto OI = [&](int pos) { return slot_list ? slot_list[pos] : pos; };
-    {
-        const int D = nd.D;
-        const float *d1k = hp + nd.off_d1k, *d1b = hp + nd.off_d1b;
-        for (int q = lane; q < PW * D; q += 64) { // dense_1 per pixel, then reduce_sum over H,W, ReLU
-            int pp = PW == 1 ? 0 : q / D, dd = PW == 1 ? q : q % D;
-            float s = 0.f, wk = d1k[dd], wb = d1b[dd];
-#pragma unroll
-            for (int p = 0; p < HW; p++) s += __builtin_fmaf(rv[pp * HW + p], wk, wb);
-            sd[q] = fmaxf(s, 0.f);
-        }
-        wave_lds_handover();
-        if constexpr (A <= 64) {
-            const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
-            for (int q = lane; q < PW * A; q += 64) { // policy dense on the last axis, reduce_sum over H,W
-                int pp = q / A, a = q % A;
-                float s = 0.f, k0 = pdk[a], k1 = pdk[A + a], kb = pdb[a];
-#pragma unroll
-                for (int p = 0; p < HW; p++)
-                    s += __builtin_fmaf(rp[2 * (pp * HW + p) + 1], k1, __builtin_fmaf(rp[2 * (pp * HW + p)], k0, kb));
-                lg[q] = s;
-            }
-            wave_lds_handover();
-        }
-    }
-#ifdef BB_STAMPS_NET
-    long long _ns = clock64();
-#endif
+    const int D = nd.D; // <= 64 (bb_load_weights)
+    const float *d1k = hp + nd.off_d1k, *d1b = hp + nd.off_d1b, *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
+    const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
+    auto lane_f = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+    // value head: dense_1 on the pooled activation (unit d on lane d), ReLU, dense_2 as an ordered fma chain, tanh
+    const float sdv = lane < D ? fmaxf(__builtin_fmaf(R, d1k[lane], (float)HW * d1b[lane]), 0.f) : 0.f;
+    float e = d2b[0];
+    for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(lane_f(sdv, dd), d2k[dd], e);
+    const float value = tanhf(e);
+    if (live && lane == 0 && value_out) value_out[pos] = value;
     if constexpr (A > 64) {
         // wide policy (DragonChess, A = 4032): see the helpers above
-        const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
-        const int D = nd.D;
-        const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
-        for (int pp = 0; pp < PW; pp++) {
-            if (pos0 + pp >= n) break;
-            int pos = OI(pos0 + pp);
-            WideHead h;
-            h.R0 = 0.f;
-            h.R1 = 0.f;
-            for (int p = 0; p < HW; p++) {
-                h.R0 += rp[2 * (pp * HW + p)];
-                h.R1 += rp[2 * (pp * HW + p) + 1];
-            }
-            {
-                float e = d2b[0];
-                for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(sd[pp * D + dd], d2k[dd], e);
-                h.value = tanhf(e);
-            }
-            if (lane == 0 && value_out) value_out[pos] = h.value;
-            NSTAMP(6);
-            if (compact) { // the caller evaluates the few probabilities it needs from (R0, R1, m, 1/sum)
-                // contract: a caller that asks for the compact form keeps nd.head in LDS (mega_dc.hip.h) -- the 3 x 4032
-                // head weights are then read with ds_read instead of flat loads
-                using LP = const __attribute__((address_space(3))) float *;
-                wide_head_stats<A, HW>(h, (LP)pdk, (LP)pdb, lane);
-                if (lane == 0) compact[pp] = h;
-                continue;
-            }
-            float *outp = policy_out ? policy_out + (size_t)pos * pstride : nullptr;
-            // the (A+63)/64 logits of a lane stay in registers from the GEMV to the normalised store: one pass over the
-            // head weights (L2-resident, shared by all positions) and ONE 16 KB write per position
-            constexpr int NPL = (A + 63) / 64;
-            float sv[NPL];
-            float m = -INFINITY;
+        WideHead h;
+        h.value = value;
+        h.R0 = R0;
+        h.R1 = R1;
+        if (compact) { // the caller evaluates the few probabilities it needs from (R0, R1, m, 1/sum)
+            // contract: a caller that asks for the compact form keeps nd.head in LDS (mega_dc.hip.h) -- the 3 x 4032
+            // head weights are then read with ds_read instead of flat loads
+            using LP = const __attribute__((address_space(3))) float *;
+            wide_head_stats<A, HW>(h, (LP)pdk, (LP)pdb, lane);
+            if (lane == 0) *compact = h;
+            return;
+        }
+        if (!live) return;
+        float *outp = policy_out ? policy_out + (size_t)pos * pstride : nullptr;
+        // the A/64 logits of a lane stay in registers from the GEMV to the normalised store: one pass over the head
+        // weights (L2-resident, shared by all positions) and ONE 16 KB write per position
+        constexpr int NPL = (A + 63) / 64;
+        float sv[NPL];
+        float m = -INFINITY;
 #pragma unroll
-            for (int k = 0; k < NPL; k++) {
-                const int a = lane + 64 * k;
-                if (a < A) {
-                    sv[k] = wide_logit<HW>(h.R0, h.R1, pdk[a], pdk[A + a], pdb[a]);
-                    if (logits_out) logits_out[(size_t)pos * A + a] = sv[k];
-                    m = fmaxf(m, sv[k]);
-                } else {
-                    sv[k] = -INFINITY;
-                }
-            }
-            m = wave_max_f32(m);
-            if (outp) {
-                float tot = 0.f;
-#pragma unroll
-                for (int k = 0; k < NPL; k++)
-                    if (lane + 64 * k < A) {
-                        sv[k] = wide_expterm(sv[k], m);
-                        tot += sv[k];
-                    }
-                tot = wave_sum_f32(tot);
-                float inv = 1.0f / tot;
-                if (noise) { // getPolicy through bb_net_eval: policy = (1-eps)*softmax + eps*Beta(alpha,1-alpha); policy /= sum(policy)
-                    // (the tree paths pass noise = 0 for wide games: they mix the draws in at expansion, tree_dc.hip.h)
-                    const uint32_t gid = game_id ? game_id[pos] : (uint32_t)noise, ser = serial ? (uint32_t)serial[pos] : (uint32_t)pos;
-                    float t2 = 0.f;
-#pragma unroll 1
-                    for (int k = 0; k < NPL; k++)
-                        if (lane + 64 * k < A) {
-                            sv[k] = (1.0f - nd.eps) * (sv[k] * inv) + nd.eps * bb_beta_noise(nd.seed, gid, ser, (uint32_t)(lane + 64 * k), nd.alpha);
-                            t2 += sv[k];
-                        }
-                    t2 = wave_sum_f32(t2);
-                    inv = 1.0f / t2;
-                }
-#pragma unroll
-                for (int k = 0; k < NPL; k++)
-                    if (lane + 64 * k < A) outp[lane + 64 * k] = sv[k] * inv;
+        for (int k = 0; k < NPL; k++) {
+            const int a = lane + 64 * k;
+            if (a < A) {
+                sv[k] = wide_logit<HW>(R0, R1, pdk[a], pdk[A + a], pdb[a]);
+                if (logits_out) logits_out[(size_t)pos * A + a] = sv[k];
+                m = fmaxf(m, sv[k]);
+            } else {
+                sv[k] = -INFINITY;
             }
         }
-        return;
-    }
-    if constexpr (A <= 64) {
-    float *nz = lg + PW * A; // [PW][A] Beta(alpha, 1-alpha) draws, one lane per (position, action)
-    if (noise) { // two lanes per (position, action): lane pair (2i, 2i+1) tries Philox pairs k and k+1 side by side
-        const float ia = nd.inv_alpha, ib = nd.inv_beta;
-        for (int base = 0; base < PW * A; base += 32) {
-            int q = base + (lane >> 1), sub = lane & 1;
-            bool live = q < PW * A && pos0 + q / A < n;
-            int a = live ? q % A : 0;
-            int pos = live ? OI(pos0 + q / A) : 0;
-            uint32_t gid = game_id ? game_id[pos] : (uint32_t)noise, ser = serial ? (uint32_t)serial[pos] : (uint32_t)pos;
+        m = wave_max_f32(m);
+        if (outp) {
+            float tot = 0.f;
+#pragma unroll
+            for (int k = 0; k < NPL; k++)
+                if (lane + 64 * k < A) {
+                    sv[k] = wide_expterm(sv[k], m);
+                    tot += sv[k];
+                }
+            tot = wave_sum_f32(tot);
+            float inv = 1.0f / tot;
+            if (noise) { // getPolicy through bb_net_eval: policy = (1-eps)*softmax + eps*Beta(alpha,1-alpha); policy /= sum(policy)
+                // (the tree paths pass noise = 0 for wide games: they mix the draws in at expansion, tree_dc.hip.h)
+                const uint32_t gid = game_id ? game_id[pos] : (uint32_t)noise, ser = serial ? (uint32_t)serial[pos] : (uint32_t)pos;
+                float t2 = 0.f;
+#pragma unroll 1
+                for (int k = 0; k < NPL; k++)
+                    if (lane + 64 * k < A) {
+                        sv[k] = (1.0f - nd.eps) * (sv[k] * inv) + nd.eps * bb_beta_noise(nd.seed, gid, ser, (uint32_t)(lane + 64 * k), nd.alpha);
+                        t2 += sv[k];
+                    }
+                t2 = wave_sum_f32(t2);
+                inv = 1.0f / t2;
+            }
+#pragma unroll
+            for (int k = 0; k < NPL; k++)
+                if (lane + 64 * k < A) outp[lane + 64 * k] = sv[k] * inv;
+        }
+    } else {
+        static_assert(A > 64 || 2 * A <= 64, "the prior-noise draws use two lanes per action");
+        // policy: action a on lane a.  softmax sums run in ascending action order over readlane broadcasts (the oracle's
+        // sequential `tot += p[a]`), so they do not depend on the lane layout.
+        const bool act = lane < A;
+        const float l = act ? wide_logit<HW>(R0, R1, pdk[act ? lane : 0], pdk[A + (act ? lane : 0)], pdb[act ? lane : 0]) : -INFINITY;
+        float m = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < A; a++) m = fmaxf(m, lane_f(l, a));
+        float pr = act ? expf(l - m) : 0.f;
+        float tot = 0.f;
+#pragma unroll
+        for (int a = 0; a < A; a++) tot += lane_f(pr, a);
+        pr = pr / tot;
+        if (noise) { // policy = (1-eps)*softmax + eps*Beta(alpha,1-alpha); policy /= sum(policy)   (NetworkFactory.py:176-182)
+            // two lanes per action: lane pair (2a, 2a+1) tries Philox pairs k and k+1 side by side
+            const float ia = nd.inv_alpha, ib = nd.inv_beta;
+            const int q = lane >> 1, sub = lane & 1;
+            const bool drawing = q < A && live;
+            const uint32_t gid = game_id ? game_id[live ? pos : 0] : (uint32_t)noise;
+            const uint32_t ser = serial ? (uint32_t)serial[live ? pos : 0] : (uint32_t)pos;
             float r = (nd.dbg & 8) ? nd.alpha : -1.0f;
-            for (uint32_t k = 0; k < 32 && __any(live && r < 0.0f); k += 2) {
-                float mine = (live && r < 0.0f) ? bb_beta_pair(nd.seed, gid, ser, (uint32_t)a, ia, ib, k + sub) : -1.0f;
+            for (uint32_t k = 0; k < 32 && __any(drawing && r < 0.0f); k += 2) {
+                float mine = (drawing && r < 0.0f) ? bb_beta_pair(nd.seed, gid, ser, (uint32_t)q, ia, ib, k + sub) : -1.0f;
                 float other = __shfl_xor(mine, 1, 64);
                 float first = sub ? other : mine, second = sub ? mine : other; // pair k before pair k+1
                 if (r < 0.0f) r = first >= 0.0f ? first : second;
             }
-            if (live && sub == 0) nz[q] = r >= 0.0f ? r : nd.alpha;
-        }
-        wave_lds_handover();
-    }
-    if constexpr (PW == 1) {
-        // one position per wave (work-queue kernel, small batches): lane a finishes action a, so the softmax costs one
-        // expf and two divisions per wave instead of 7 and 14 on lane 0 (vector issue is what the persistent kernel is
-        // short of).  The oracle's ordered sums (tot += p[a], a ascending) run over v_readlane broadcasts: same values,
-        // same order, bit-identical to the sequential form below.
-        if (pos0 < n) {
-            const int D = nd.D, pos = OI(pos0);
-            const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
-            const bool act = lane < A;
-            const float l = act ? lg[lane] : -INFINITY;
-            auto lane_f = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
-            float m = -INFINITY;
-#pragma unroll
-            for (int a = 0; a < A; a++) m = fmaxf(m, lane_f(l, a));
-            float pr = act ? expf(l - m) : 0.f;
-            float tot = 0.f;
-#pragma unroll
-            for (int a = 0; a < A; a++) tot += lane_f(pr, a);
-            pr = pr / tot;
-            if (noise) { // policy = (1-eps)*softmax + eps*Beta(alpha,1-alpha); policy /= sum(policy)
-                pr = (1.0f - nd.eps) * pr + nd.eps * (act ? nz[lane] : 0.f);
-                float t2 = 0.f;
-#pragma unroll
-                for (int a = 0; a < A; a++) t2 += lane_f(pr, a);
-                pr = pr / t2;
-            }
-            if (act && logits_out) logits_out[(size_t)pos * A + lane] = l;
-            if (act && policy_out) policy_out[(size_t)pos * pstride + lane] = pr;
-            if (lane == 0 && value_out) {
-                float e = d2b[0];
-                for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(sd[dd], d2k[dd], e);
-                value_out[pos] = tanhf(e);
-            }
-        }
-    } else
-    if (lane < PW && pos0 + lane < n) { // one lane finishes each position (sequential, oracle order)
-        const int D = nd.D, pp = lane, pos = OI(pos0 + lane);
-        const float *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
-        float e = d2b[0];
-        for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(sd[pp * D + dd], d2k[dd], e);
-        if (value_out) value_out[pos] = tanhf(e);
-        float m = -INFINITY;
-        for (int a = 0; a < A; a++) m = fmaxf(m, lg[pp * A + a]);
-        float pr[A];
-        float tot = 0.f;
-#pragma unroll
-        for (int a = 0; a < A; a++) {
-            float l = lg[pp * A + a];
-            if (logits_out) logits_out[(size_t)pos * A + a] = l;
-            pr[a] = expf(l - m);
-            tot += pr[a];
-        }
-#pragma unroll
-        for (int a = 0; a < A; a++) pr[a] = pr[a] / tot;
-        if (noise) { // policy = (1-eps)*softmax + eps*Beta(alpha,1-alpha); policy /= sum(policy)
+            r = r >= 0.0f ? r : nd.alpha;
+            const float nz = __shfl(r, 2 * (act ? lane : 0), 64); // action a's draw sits on lane 2a
+            pr = (1.0f - nd.eps) * pr + nd.eps * (act ? nz : 0.f);
             float t2 = 0.f;
 #pragma unroll
-            for (int a = 0; a < A; a++) {
-                pr[a] = (1.0f - nd.eps) * pr[a] + nd.eps * nz[pp * A + a];
-                t2 += pr[a];
-            }
-#pragma unroll
-            for (int a = 0; a < A; a++) pr[a] = pr[a] / t2;
+            for (int a = 0; a < A; a++) t2 += lane_f(pr, a);
+            pr = pr / t2;
         }
-        if (policy_out)
-#pragma unroll
-            for (int a = 0; a < A; a++) policy_out[(size_t)pos * pstride + a] = pr[a];
+        if (live && act && logits_out) logits_out[(size_t)pos * A + lane] = l;
+        if (live && act && policy_out) policy_out[(size_t)pos * pstride + lane] = pr;
     }
+}
+
+// The same for PW positions whose per-pixel head activations sit in memory (LDS): rv[PW*HW], rp[PW*HW][2].
+template <class G, int PW>
+__device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0, const int *slot_list, const float *rv,
+                                              const float *rp, const uint32_t *game_id, const int32_t *serial, int noise,
+                                              float *value_out, float *logits_out, float *policy_out, int pstride,
+                                              WideHead *compact = nullptr) {
+    constexpr int HW = G::H * G::W;
+    static_assert(HW <= 64, "one lane per pixel of a position");
+    const int lane = threadIdx.x & 63;
+    for (int pp = 0; pp < PW; pp++) {
+        const bool live = pos0 + pp < n;
+        if (!live && !compact) break;
+        const int pos = live ? (slot_list ? slot_list[pos0 + pp] : pos0 + pp) : 0;
+        const float x = lane < HW ? rv[pp * HW + lane] : 0.f;
+        const float x0 = lane < HW ? rp[2 * (pp * HW + lane)] : 0.f, x1 = lane < HW ? rp[2 * (pp * HW + lane) + 1] : 0.f;
+        head_one<G>(nd, pooled_sum(x), pooled_sum(x0), pooled_sum(x1), pos, live, game_id, serial, noise, value_out, logits_out,
+                    policy_out, pstride, compact ? compact + pp : nullptr);
     }
 }
 
@@ -622,44 +566,56 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
     NSTAMP(2);
     // ---- heads (tower output is in actA; actB and inp are scratch now) --------------------------
     const float *hp = nd.head;
-    float *rv = actB;               // [PW*HW] value-conv output
-    float *rp = actB + PW * HW;     // [PW*HW][2] policy-conv output
-    float *sd = rp + 2 * PW * HW;   // [PW][D]
-    float *lg = sd + PW * nd.D;     // [PW][A]
-    {
-        const float *vk = hp + nd.off_vk, *v3 = hp + nd.off_v3, *pk = hp + nd.off_pk, *p6 = hp + nd.off_p6;
-        for (int q = lane; q < PW * HW; q += 64) {
-            int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
-            const float *xp = actA + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * 4;
-            float av = v3[0], a0 = p6[0], a1 = p6[1];
+    const float *vk = hp + nd.off_vk, *v3 = hp + nd.off_v3, *pk = hp + nd.off_pk, *p6 = hp + nd.off_p6;
+    auto head_convs = [&](int q, float &o, float &o0, float &o1) __attribute__((always_inline)) { // 1x1 convs + BN + ReLU of pixel q
+        int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
+        const float *xp = actA + (pp * SLOTS + (y + 1) * (W + 1) + (x + 1)) * 4;
+        float av = v3[0], a0 = p6[0], a1 = p6[1];
 #pragma unroll
-            for (int c4 = 0; c4 < 4; c4++) {
-                f32x4 xv = *(const f32x4 *)(xp + c4 * PLANE);
+        for (int c4 = 0; c4 < 4; c4++) {
+            f32x4 xv = *(const f32x4 *)(xp + c4 * PLANE);
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    int c = 4 * c4 + r;
-                    av = __builtin_fmaf(xv[r], vk[c], av);
-                    a0 = __builtin_fmaf(xv[r], pk[2 * c], a0);
-                    a1 = __builtin_fmaf(xv[r], pk[2 * c + 1], a1);
-                }
+            for (int r = 0; r < 4; r++) {
+                int c = 4 * c4 + r;
+                av = __builtin_fmaf(xv[r], vk[c], av);
+                a0 = __builtin_fmaf(xv[r], pk[2 * c], a0);
+                a1 = __builtin_fmaf(xv[r], pk[2 * c + 1], a1);
             }
-            rv[q] = fmaxf(__builtin_fmaf(av, v3[1], v3[2]), 0.f);
-            rp[2 * q] = fmaxf(__builtin_fmaf(a0, p6[2], p6[4]), 0.f);
-            rp[2 * q + 1] = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
         }
-    }
-    wave_lds_handover();
-    NSTAMP(3);
-    net_head_tail<G, PW>(nd, n, pos0, slot_list, rv, rp, sd, lg, game_id, serial, noise, value_out, logits_out, policy_out,
-                         pstride, compact);
-    NSTAMP(4);
-    if constexpr (A > 64) return; // (wide games never ran the scratch restore below)
-    NSTAMP(5);
-    if (!zero_lds) { // persistent caller: the head scratch overlaid actB's halo slots -- restore the zeros
-        const int used = 3 * PW * HW + PW * nd.D + 2 * PW * (A <= 64 ? A : 0);
+        o = fmaxf(__builtin_fmaf(av, v3[1], v3[2]), 0.f);
+        o0 = fmaxf(__builtin_fmaf(a0, p6[2], p6[4]), 0.f);
+        o1 = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
+    };
+    if constexpr (PW == 1) {
+        // one position per wave: pixel p's head activations stay in lane p's registers, pooled by butterflies -- no LDS scratch
+        static_assert(HW <= 64, "one lane per pixel");
+        float x = 0.f, x0 = 0.f, x1 = 0.f;
+        if (lane < HW) head_convs(lane, x, x0, x1);
+        NSTAMP(3);
+        const bool live = pos0 < n;
+        head_one<G>(nd, pooled_sum(x), pooled_sum(x0), pooled_sum(x1), live ? OI(pos0) : 0, live, game_id, serial, noise, value_out,
+                    logits_out, policy_out, pstride, compact);
+        NSTAMP(4);
+    } else {
+        float *rv = actB;               // [PW*HW] value-conv output
+        float *rp = actB + PW * HW;     // [PW*HW][2] policy-conv output
+        for (int q = lane; q < PW * HW; q += 64) {
+            float x, x0, x1;
+            head_convs(q, x, x0, x1);
+            rv[q] = x;
+            rp[2 * q] = x0;
+            rp[2 * q + 1] = x1;
+        }
         wave_lds_handover();
-        for (int i = lane; i < used; i += 64) actB[i] = 0.f;
-        wave_lds_handover();
+        NSTAMP(3);
+        net_head_tail<G, PW>(nd, n, pos0, slot_list, rv, rp, game_id, serial, noise, value_out, logits_out, policy_out, pstride,
+                             compact);
+        NSTAMP(4);
+        if (!zero_lds) { // persistent caller: the head scratch overlaid actB's halo slots -- restore the zeros
+            wave_lds_handover();
+            for (int i = lane; i < 3 * PW * HW; i += 64) actB[i] = 0.f;
+            wave_lds_handover();
+        }
     }
 }
 

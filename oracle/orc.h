@@ -123,6 +123,8 @@ int  orc_dc_is_legal(const orc_state *st, int r1, int c1, int r2, int c2);
 void orc_hash_eval(int game, uint64_t salt, const orc_state *st, float *value, float *policy);
 void orc_net_forward(const orc_net *w, const int8_t *boards /*[n][H][W][C]*/, int n,
                      float *value /*[n]*/, float *logits /*[n][A]*/, float *policy /*[n][A] softmax*/);
+/* the same network with the heads in the reference's literal op order (dense per pixel, then reduce_sum): see orc_net.c */
+void orc_net_forward_perpixel(const orc_net *w, const int8_t *boards, int n, float *value, float *logits, float *policy);
 double orc_np_sum(const double *a, int n); /* numpy pairwise add.reduce */
 void orc_philox(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
 double orc_u53(uint64_t key, uint32_t game_id, uint32_t ply);

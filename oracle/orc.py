@@ -89,6 +89,7 @@ def lib():
     L.orc_game_equal.restype = C.c_int
     L.orc_hash_eval.argtypes = [C.c_int, C.c_uint64, SP, _FP, C.c_void_p]
     L.orc_net_forward.argtypes = [C.POINTER(Net), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_net_forward_perpixel.argtypes = [C.POINTER(Net), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_np_sum.argtypes = [C.c_void_p, C.c_int]
     L.orc_np_sum.restype = C.c_double
     L.orc_philox.argtypes = [C.c_uint64] + [C.c_uint32] * 4 + [C.POINTER(C.c_uint32 * 4)]
@@ -196,15 +197,17 @@ class NetWeights:
             setattr(self.c, k, self.arrays[k].ctypes.data_as(_FP))
 
 
-def net_forward(w, boards):
+def net_forward(w, boards, perpixel=False):
+    """Network forward.  Default: the pooled statement of the heads (what the HIP kernels compute); perpixel=True: the
+    reference's literal op order (dense per pixel, then reduce_sum) -- see orc_net.c."""
     boards = np.ascontiguousarray(boards, dtype=np.int8)
     n = boards.shape[0]
     A = w.shape[6]
     value = np.zeros(n, dtype=np.float32)
     logits = np.zeros((n, A), dtype=np.float32)
     policy = np.zeros((n, A), dtype=np.float32)
-    lib().orc_net_forward(C.byref(w.c), boards.ctypes.data, n, value.ctypes.data, logits.ctypes.data,
-                          policy.ctypes.data)
+    fn = lib().orc_net_forward_perpixel if perpixel else lib().orc_net_forward
+    fn(C.byref(w.c), boards.ctypes.data, n, value.ctypes.data, logits.ctypes.data, policy.ctypes.data)
     return value, logits, policy
 
 

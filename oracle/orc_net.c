@@ -84,8 +84,27 @@ static void conv3x3(const float *in, float *out, const float *skip, int H, int W
     free(acc);
 }
 
-void orc_net_forward(const orc_net *w, const int8_t *boards, int n, float *value, float *logits,
-                     float *policy) {
+/* reduce_sum over H, W as a fixed pairwise tree: the values sit in slots 0..n-1 of a 64-slot vector (the rest 0.0) and are
+ * folded with strides 32, 16, ..., 1 -- the xor butterfly of a 64-lane wave, which is how the HIP kernels form the sum
+ * (blackbird_amd/csrc/net.hip.h: pooled_sum).  TensorFlow leaves the order of a reduce_sum unspecified. */
+static float tree_sum64(const float *x, int n, int stride) {
+    float t[64];
+    for (int i = 0; i < 64; i++) t[i] = i < n ? x[(size_t)i * stride] : 0.f;
+    for (int o = 32; o >= 1; o >>= 1)
+        for (int i = 0; i < o; i++) t[i] = t[i] + t[i + o];
+    return t[0];
+}
+
+/* The forward pass in two statements of the heads, equal in exact arithmetic:
+ *   pooled = 0  the reference's op order: dense on the last axis of [H, W, c], THEN reduce_sum over H, W
+ *               (NetworkFactory.py:125-131, 165-169), sums in row-major pixel order;
+ *   pooled = 1  reduce_sum over H, W first (tree_sum64), then the dense layer on the pooled activations:
+ *               relu(k[d] * R + HW * b[d]) and k1[a] * R1 + (k0[a] * R0 + HW * b[a]).
+ * orc_net_forward is the pooled statement -- the one the HIP kernels implement, bit for bit up to expf/tanhf;
+ * orc_net_forward_perpixel keeps the literal op order; tests/test_oracle_net.py holds the two against each other
+ * (<= 1e-6 relative) and both against independent PyTorch ops. */
+static void net_forward_impl(const orc_net *w, const int8_t *boards, int n, float *value, float *logits, float *policy,
+                             int pooled) {
     int H = w->H, W = w->W, C = w->C, F = w->F, R = w->R, D = w->D, A = w->A;
     int HW = H * W;
     float *x0 = (float *)malloc(sizeof(float) * (size_t)HW * C);
@@ -126,11 +145,20 @@ void orc_net_forward(const orc_net *w, const int8_t *boards, int n, float *value
                 rv[p] = v > 0.f ? v : 0.f;
             }
             float e = w->v_d2_b[0];
-            for (int d = 0; d < D; d++) {
-                float s = 0.f; /* dense_1 per pixel (:125-127) then reduce_sum over H,W (:129-131) */
-                for (int p = 0; p < HW; p++) s += fmaf(rv[p], w->v_d1_k[d], w->v_d1_b[d]);
-                s = s > 0.f ? s : 0.f;
-                e = fmaf(s, w->v_d2_k[d], e);
+            if (pooled) { /* dense_1 after the pool: relu(k[d] * sum_p rv[p] + HW * b[d]) */
+                float Rv = tree_sum64(rv, HW, 1);
+                for (int d = 0; d < D; d++) {
+                    float s = fmaf(Rv, w->v_d1_k[d], (float)HW * w->v_d1_b[d]);
+                    s = s > 0.f ? s : 0.f;
+                    e = fmaf(s, w->v_d2_k[d], e);
+                }
+            } else {
+                for (int d = 0; d < D; d++) {
+                    float s = 0.f; /* dense_1 per pixel (:125-127) then reduce_sum over H,W (:129-131) */
+                    for (int p = 0; p < HW; p++) s += fmaf(rv[p], w->v_d1_k[d], w->v_d1_b[d]);
+                    s = s > 0.f ? s : 0.f;
+                    e = fmaf(s, w->v_d2_k[d], e);
+                }
             }
             value[b] = tanhf(e);
         }
@@ -146,10 +174,19 @@ void orc_net_forward(const orc_net *w, const int8_t *boards, int n, float *value
                     rp[p * 2 + q] = v > 0.f ? v : 0.f;
                 }
             float m = -INFINITY;
+            float R0 = 0.f, R1 = 0.f;
+            if (pooled) {
+                R0 = tree_sum64(rp, HW, 2);
+                R1 = tree_sum64(rp + 1, HW, 2);
+            }
             for (int a = 0; a < A; a++) {
-                float s = 0.f; /* dense on the last axis (:165-166) then reduce_sum over H,W (:168-169) */
-                for (int p = 0; p < HW; p++)
-                    s += fmaf(rp[p * 2 + 1], w->p_d_k[A + a], fmaf(rp[p * 2 + 0], w->p_d_k[a], w->p_d_b[a]));
+                float s = 0.f;
+                if (pooled) { /* dense after the pool: k1[a] * R1 + (k0[a] * R0 + HW * b[a]) */
+                    s = fmaf(R1, w->p_d_k[A + a], fmaf(R0, w->p_d_k[a], (float)HW * w->p_d_b[a]));
+                } else { /* dense on the last axis (:165-166) then reduce_sum over H,W (:168-169) */
+                    for (int p = 0; p < HW; p++)
+                        s += fmaf(rp[p * 2 + 1], w->p_d_k[A + a], fmaf(rp[p * 2 + 0], w->p_d_k[a], w->p_d_b[a]));
+                }
                 lg[a] = s;
                 if (s > m) m = s;
             }
@@ -164,4 +201,12 @@ void orc_net_forward(const orc_net *w, const int8_t *boards, int n, float *value
         }
     }
     free(x0); free(xa); free(xb); free(xc); free(sc); free(sh); free(rv); free(rp); free(lg);
+}
+
+void orc_net_forward(const orc_net *w, const int8_t *boards, int n, float *value, float *logits, float *policy) {
+    net_forward_impl(w, boards, n, value, logits, policy, 1);
+}
+
+void orc_net_forward_perpixel(const orc_net *w, const int8_t *boards, int n, float *value, float *logits, float *policy) {
+    net_forward_impl(w, boards, n, value, logits, policy, 0);
 }

@@ -63,13 +63,16 @@ def random_boards(rng, n, H, Wd, C):
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 @pytest.mark.parametrize("perturb", [False, True])
-def test_oracle_net_vs_torch(orc, case, perturb):
+@pytest.mark.parametrize("perpixel", [False, True], ids=["pooled", "perpixel"])
+def test_oracle_net_vs_torch(orc, case, perturb, perpixel):
+    """Both statements of the heads (orc_net.c: pooled = what the HIP kernels compute; per pixel = the reference's literal
+    op order) against the PyTorch statement, which itself follows the reference's op order."""
     _, H, Wd, C, F, R, D, A = case
     w = W.init_weights(C, F, R, D, A, seed=3, perturb=perturb)
     ow = orc.NetWeights(H, Wd, C, F, R, D, A, W.flatten(w))
     rng = np.random.RandomState(1)
     boards = random_boards(rng, 6, H, Wd, C)
-    v, lg, pol = orc.net_forward(ow, boards)
+    v, lg, pol = orc.net_forward(ow, boards, perpixel=perpixel)
     tv, tl, tp = torch_forward(w, boards)
     # tolerance 1e-5 (north star), relative to max(1,|x|) for logits
     assert np.max(np.abs(v - tv)) <= 1e-5
@@ -90,3 +93,20 @@ def test_pool_then_dense_identity(orc):
     ow2 = orc.NetWeights(H, Wd, C, F, R, D, A, W.flatten(w2))
     _, lg0, _ = orc.net_forward(ow2, boards)
     assert np.allclose(lg - lg0, H * Wd * w["policy/policy/bias"][None, :], atol=1e-4)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_pooled_heads_equal_per_pixel_heads(orc, case):
+    """`dense` on the last axis then reduce_sum over H, W (the reference's op order) vs reduce_sum first and `dense` on the
+    pooled activations (what the product and the oracle's default compute): the same numbers to float32 rounding -- far
+    inside the 1e-5 the network outputs are held to."""
+    _, H, Wd, C, F, R, D, A = case
+    w = W.init_weights(C, F, R, D, A, seed=8, perturb=True)
+    ow = orc.NetWeights(H, Wd, C, F, R, D, A, W.flatten(w))
+    boards = random_boards(np.random.RandomState(4), 16, H, Wd, C)
+    v0, l0, p0 = orc.net_forward(ow, boards, perpixel=True)
+    v1, l1, p1 = orc.net_forward(ow, boards)
+    assert np.max(np.abs(v0 - v1)) <= 2e-6
+    assert np.max(np.abs(l0 - l1) / np.maximum(1.0, np.abs(l0))) <= 2e-6
+    assert np.max(np.abs(p0 - p1)) <= 2e-6
+    assert not np.array_equal(l0, l1) or H * Wd < 4  # (they are different roundings, not the same code path)
