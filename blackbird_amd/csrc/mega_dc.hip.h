@@ -49,6 +49,49 @@ __device__ __attribute__((noinline)) void dc_fused_move(const TreeDev &d_, const
     __threadfence_block();
 }
 
+// Per-game control state of the four games of a workgroup, kept in LDS for the launch (as the Connect4 work-queue kernel
+// does, mega2.hip.h): every scalar the tree phases read first and write last, the recorded path and the leaf mailbox.
+// A lone wave per SIMD pays a full memory round trip for each of these otherwise (the phases open with a dozen dependent
+// loads and close with as many stores).  The tree code indexes these arrays with the wave's number in the workgroup;
+// TreeDev::pool_g0 carries the workgroup's first slot for the node and edge pools, which stay in HBM.
+struct DCShadow {
+    static constexpr int GW = 4, MP = DragonChess::MAXPATH;
+    int32_t root[GW], root_N[GW], n_nodes[GW], ply[GW], sims_left[GW], pend_leaf[GW], pend_expand[GW], path_len[GW],
+        game_lid[GW], sim_serial[GW], leaf_serial[GW], used[GW];
+    uint32_t leaf_game_id[GW];
+    float root_W[GW], eval_value[GW];
+    uint64_t evals[GW];
+    uint64_t ctr[GW * 8];
+    DCState leaf_state[GW];
+    uint32_t path[GW * MP], path_edge[GW * MP];
+    int8_t root_pp[GW];
+
+#define BB_DC_SHADOW_ARRAYS(X)                                                                                       \
+    X(d, root, 1) X(d, root_N, 1) X(d, n_nodes, 1) X(d, ply, 1) X(d, sims_left, 1) X(d, pend_leaf, 1) X(d, pend_expand, 1) \
+    X(d, path_len, 1) X(d, game_lid, 1) X(d, sim_serial, 1) X(d, leaf_serial, 1) X(d, leaf_game_id, 1) X(d, root_W, 1)   \
+    X(d, eval_value, 1) X(d, evals, 1) X(d, ctr, 8) X(d, path, MP) X(d, root_pp, 1) X(E, used, 1) X(E, path_edge, MP)
+
+    __device__ __forceinline__ void load(const TreeDev &d, const DCEdges &E, int g0, int n, int nthreads) {
+#define X(o, f, per) for (int i = threadIdx.x; i < n * (per); i += nthreads) f[i] = o.f[(size_t)g0 * (per) + i];
+        BB_DC_SHADOW_ARRAYS(X)
+#undef X
+        for (int i = threadIdx.x; i < n; i += nthreads) leaf_state[i] = ((const DCState *)d.leaf_state)[g0 + i];
+    }
+    __device__ __forceinline__ void store(const TreeDev &d, const DCEdges &E, int g0, int n, int nthreads) {
+#define X(o, f, per) for (int i = threadIdx.x; i < n * (per); i += nthreads) o.f[(size_t)g0 * (per) + i] = f[i];
+        BB_DC_SHADOW_ARRAYS(X)
+#undef X
+        for (int i = threadIdx.x; i < n; i += nthreads) ((DCState *)d.leaf_state)[g0 + i] = leaf_state[i];
+    }
+    __device__ __forceinline__ void point(TreeDev &d, DCEdges &E, int g0) { // d, E: copies of the kernel arguments
+#define X(o, f, per) o.f = f;
+        BB_DC_SHADOW_ARRAYS(X)
+#undef X
+        d.leaf_state = leaf_state;
+        d.pool_g0 = g0;
+    }
+};
+
 __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdges E_arg, NetDev nd_arg, int plies, int sims, int noise_on) {
     using NG = NetGeom<DragonChess, 1>;
     // the tree's scratch (the 4032-float policy image) and the network's activations are never live together
@@ -64,10 +107,17 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
     __shared__ TreeDev s_d;
     __shared__ DCEdges s_E;
     __shared__ NetDev s_nd;
+    __shared__ DCShadow shadow;
+    const int g0 = blockIdx.x * 4;
+    const int n_mine = d_arg.n_slots - g0 < 4 ? d_arg.n_slots - g0 : 4;
+    shadow.load(d_arg, E_arg, g0, n_mine, blockDim.x);
     for (int i = threadIdx.x; i < nd_arg.head_floats; i += blockDim.x) s_head[i] = nd_arg.head[i]; // (host: head_floats <= DC_HEAD_FLOATS)
     if (threadIdx.x == 0) {
-        s_d = d_arg;
-        s_E = E_arg;
+        TreeDev dl = d_arg;
+        DCEdges El = E_arg;
+        shadow.point(dl, El, g0);
+        s_d = dl;
+        s_E = El;
         s_nd = nd_arg;
         s_nd.head = s_head;
     }
@@ -82,8 +132,9 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
     const TreeDev &d = s_d;
     const DCEdges &E = s_E;
     const NetDev &nd = s_nd;
-    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (g >= d.n_slots) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = wv; // the wave's game, by its number in the workgroup: index of the LDS copies (pools: + pool_g0)
+    const bool mine = g0 + wv < d.n_slots;
     float *tl = (float *)lds_all[wv];
     float *nl = (float *)lds_all[wv];
     DCHeadLocal *hl = &s_hl[wv];
@@ -94,7 +145,7 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
     if (lane < 16) ((unsigned long long *)(lds + DC_STAMP_OFF))[lane] = 0;
 #endif
     __threadfence_block();
-    for (int p = 0; p < plies; p++) {
+    for (int p = 0; mine && p < plies; p++) {
         if (d.game_lid[g] < 0) break; // this slot has played its last game
         for (int s = 0; s < sims; s++) {
 #ifdef BB_STAMPS
@@ -115,7 +166,9 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
         dc_fused_move(d, E, g, lane, tl, hl);
     }
 #ifdef BB_STAMPS
-    if (lane == 0 && d.stamps)
-        for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[(size_t)(g & 63) * 16 + i], ((unsigned long long *)(lds + DC_STAMP_OFF))[i]);
+    if (mine && lane == 0 && d.stamps)
+        for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[(size_t)((g0 + g) & 63) * 16 + i], ((unsigned long long *)(lds + DC_STAMP_OFF))[i]);
 #endif
+    __syncthreads();
+    shadow.store(d_arg, E_arg, g0, n_mine, blockDim.x); // hand the per-game state back to HBM
 }

@@ -228,7 +228,7 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
         e2 = clock64();
 #endif
     }
-    size_t base = (size_t)g * E.edge_cap + off;
+    size_t base = (size_t)(g + d.pool_g0) * E.edge_cap + off;
 #pragma unroll
     for (int i = 0; i < MPL; i++)
         if (mya[i] >= 0) {
@@ -288,13 +288,13 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const long long a_r1 = clock64();
 #endif
-    DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
+    DCNode *pool = (DCNode *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     DCNode *node = pool + leaf;
     DCState st = ((const DCState *)d.leaf_state)[g];
     // the path's statistics (edges and nodes above the leaf: the expansion below touches none of them)
     const bool on_path = lane < plen;
     DCNode *my_nd = pool + (on_path ? pn0 : 0u);
-    const size_t my_e = (size_t)g * E.edge_cap + (on_path ? (pe0 & 0x3FFFFFFFu) : 0u);
+    const size_t my_e = (size_t)(g + d.pool_g0) * E.edge_cap + (on_path ? (pe0 & 0x3FFFFFFFu) : 0u);
     int my_n = 0, my_all = 0;
     float my_w = 0.f;
     if (on_path) {
@@ -343,7 +343,7 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
         DCNode *nd = pool + pn[k];
         uint32_t ew = pe[k];
         int pl = (int)(ew >> 30);
-        size_t e = (size_t)g * E.edge_cap + (ew & 0x3FFFFFFFu);
+        size_t e = (size_t)(g + d.pool_g0) * E.edge_cap + (ew & 0x3FFFFFFFu);
         int n = E.e[e].N + 1, all = nd->all + 1;
         float w = E.e[e].W + ((pl == prev) ? v01 : vflip);
         E.e[e].N = n;
@@ -414,7 +414,7 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
 #else
 #define QS(acc) do {} while (0)
 #endif
-    DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
+    DCNode *pool = (DCNode *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     uint32_t *pn = d.path + (size_t)g * DragonChess::MAXPATH;
     uint32_t *pe = E.path_edge + (size_t)g * DragonChess::MAXPATH;
     int depth = 0, expand = 0, overflow = 0, term_leaf = 0;
@@ -461,7 +461,7 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
         // PUCT over the node's edges, 64 per pass
         double bu = -1.0;
         int bi = -1, bchild = CHILD_NONE, bact = 0;
-        size_t base = (size_t)g * E.edge_cap + edge_off;
+        size_t base = (size_t)(g + d.pool_g0) * E.edge_cap + edge_off;
 #ifdef BB_STAMPS
         if (lane < n_edges) {
             DCEdge probe = E.e[base + lane];
@@ -591,12 +591,12 @@ __global__ void __launch_bounds__(256) k_dc_tree_apply(TreeDev d, DCEdges E) {
 // lane 0 walks the (<=144) edges: the np.random.choice law needs the sequential cumsum
 __device__ int dc_choose_move(const TreeDev &d, const DCEdges &E, int g, int lane, double temp, double u, int &total,
                               int &edge_out) {
-    DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
+    DCNode *pool = (DCNode *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     DCNode *node = pool + d.root[g];
     int act = -3, tot = 0, eo = -1;
     if (lane == 0 && (node->flags & NODE_EXPANDED)) {
         int n = node->n_edges;
-        size_t base = (size_t)g * E.edge_cap + node->edge_off;
+        size_t base = (size_t)(g + d.pool_g0) * E.edge_cap + node->edge_off;
         for (int k = 0; k < n; k++) tot += E.e[base + k].N;
         if (temp == 0.0) {
             double bu = -1.0;
@@ -658,9 +658,9 @@ __global__ void __launch_bounds__(256) k_dc_sample(TreeDev d, DCEdges E, double 
     double u = d.in_u ? d.in_u[g] : bb_u53(d.seed, d.first_game_id + (uint32_t)d.game_lid[g], (uint32_t)d.ply[g]);
     int total, eo;
     int act = dc_choose_move(d, E, g, lane, temp, u, total, eo);
-    DCNode *node = (DCNode *)d.nodes + (size_t)g * d.node_cap + d.root[g];
+    DCNode *node = (DCNode *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap + d.root[g];
     if (node->flags & NODE_EXPANDED) {
-        size_t base = (size_t)g * E.edge_cap + node->edge_off;
+        size_t base = (size_t)(g + d.pool_g0) * E.edge_cap + node->edge_off;
         for (int k = lane; k < node->n_edges; k += 64) {
             if (d.out_child_plays) d.out_child_plays[(size_t)g * S + k] = E.e[base + k].N;
             if (d.out_child_value) d.out_child_value[(size_t)g * S + k] = E.e[base + k].W;
@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(256) k_dc_sample(TreeDev d, DCEdges E, double 
 }
 
 __device__ __forceinline__ void dc_reset_slot(const TreeDev &d, const DCEdges &E, int g, int lid, const DCState &st) {
-    DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
+    DCNode *pool = (DCNode *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     pool->st = st;
     pool->flags = (int)st.player << 4;
     pool->n_edges = 0;
@@ -702,7 +702,7 @@ __device__ __forceinline__ void dc_reset_slot(const TreeDev &d, const DCEdges &E
 
 // _moveRoot by action id (all lanes call; lane 0 writes)
 __device__ void dc_advance_root(const TreeDev &d, const DCEdges &E, int g, int lane, int action, DCState &new_st) {
-    DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
+    DCNode *pool = (DCNode *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     DCNode *node = pool + d.root[g];
     DCState st = node->st;
     if (!(node->flags & NODE_EXPANDED)) {
@@ -712,7 +712,7 @@ __device__ void dc_advance_root(const TreeDev &d, const DCEdges &E, int g, int l
         return;
     }
     int n = node->n_edges;
-    size_t base = (size_t)g * E.edge_cap + node->edge_off;
+    size_t base = (size_t)(g + d.pool_g0) * E.edge_cap + node->edge_off;
     int k = -1;
     for (int i = lane; i < n; i += 64)
         if ((int)E.e[base + i].act == action) k = i;
@@ -776,7 +776,7 @@ __global__ void __launch_bounds__(256) k_dc_set_roots(TreeDev d, DCEdges E, int 
 __global__ void __launch_bounds__(256) k_dc_get_roots(TreeDev d, DCState *out) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.n_slots) return;
-    out[g] = ((DCNode *)d.nodes + (size_t)g * d.node_cap + d.root[g])->st;
+    out[g] = ((DCNode *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap + d.root[g])->st;
 }
 
 __global__ void __launch_bounds__(256) k_dc_selfplay_begin(TreeDev d, DCEdges E) {
@@ -799,7 +799,7 @@ __device__ void dc_write_example(const TreeDev &d, const DCEdges &E, int lid, in
     uint32_t *vis = (uint32_t *)(p + sizeof(ExampleHdr) + sizeof(DCState));
     uint16_t *act = (uint16_t *)(p + sizeof(ExampleHdr) + sizeof(DCState) + 4 * S);
     int n = terminal_example ? 0 : node->n_edges;
-    size_t base = terminal_example ? 0 : (size_t)g * E.edge_cap + node->edge_off;
+    size_t base = terminal_example ? 0 : (size_t)(g + d.pool_g0) * E.edge_cap + node->edge_off;
     for (int k = lane; k < S; k += 64) {
         vis[k] = k < n ? (uint32_t)E.e[base + k].N : 0u;
         act[k] = k < n ? E.e[base + k].act : (uint16_t)0xFFFF;
@@ -824,7 +824,7 @@ __device__ void dc_selfplay_move_body(const TreeDev &d, const DCEdges &E, int g,
     __threadfence_block();
     int lid = d.game_lid[g];
     if (lid < 0) return;
-    DCNode *pool = (DCNode *)d.nodes + (size_t)g * d.node_cap;
+    DCNode *pool = (DCNode *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     DCNode *root = pool + d.root[g];
     DCState st = root->st;
     uint32_t gid = d.first_game_id + (uint32_t)lid;
