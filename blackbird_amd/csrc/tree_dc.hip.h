@@ -158,12 +158,67 @@ __device__ __forceinline__ double dc_np_sum(const float *a, int lane) {
     return __shfl(v, 0, 64);
 }
 
+// ---- a position spread over the wave: lane k holds square k, the scalars are uniform ---------------------------------------
+// A DCState held in registers is 20 VGPRs that the game rules index DYNAMICALLY (b[sq1], b[sq2], ray walks): the compiler
+// answers with scratch memory, and the descent paid several scratch round trips per created node.  With one square per
+// lane a move is two selects around a v_readlane, the castle flags are six readlanes and "is a king missing" is a ballot.
+struct DCLane {
+    int sq;                   // piece code on this lane's square (DragonChess.py:12-19)
+    int player, prev, castle; // uniform; castle = bit i <-> castle[i] (wK wQ bK bQ)
+};
+__device__ __forceinline__ DCLane dc_lane_load(const DCState *p, int lane) {
+    DCLane l;
+    l.sq = p->b[lane];
+    const uint32_t w0 = *(const uint32_t *)&p->player, w1 = *(const uint16_t *)&p->castle[2]; // player, prev, castle[0..1] | castle[2..3]
+    l.player = (int)(int8_t)(w0 & 0xff);
+    l.prev = (int)(int8_t)((w0 >> 8) & 0xff);
+    l.castle = (int)(((w0 >> 16) & 1u) | (((w0 >> 24) & 1u) << 1) | ((w1 & 1u) << 2) | (((w1 >> 8) & 1u) << 3));
+    return l;
+}
+__device__ __forceinline__ void dc_lane_store(DCState *p, const DCLane &l, int lane) {
+    p->b[lane] = (int8_t)l.sq;
+    if (lane == 0) { // player, prev, castle[4], 10 pad bytes (zero, as every DCState in the pools has them)
+        uint32_t *w = (uint32_t *)&p->player;
+        w[0] = (uint32_t)(l.player & 0xff) | ((uint32_t)(l.prev & 0xff) << 8) | ((uint32_t)(l.castle & 1) << 16) | ((uint32_t)((l.castle >> 1) & 1) << 24);
+        w[1] = (uint32_t)((l.castle >> 2) & 1) | ((uint32_t)((l.castle >> 3) & 1) << 8);
+        w[2] = 0;
+        w[3] = 0;
+    }
+}
+// ApplyAction (DragonChess.py:127-159 + Move :172-214) for a move KNOWN to be legal (it comes from the node's edge list),
+// then Winner() (:161-167): -1 none, 1, 2.  `action` is wave-uniform.
+__device__ __forceinline__ int dc_lane_apply(DCLane &l, int action, int lane) {
+    int sq1, sq2;
+    DragonChess::action_squares(__builtin_amdgcn_readfirstlane(action), sq1, sq2);
+    const int moved = __builtin_amdgcn_readlane(l.sq, sq1);
+    l.sq = lane == sq2 ? moved : (lane == sq1 ? 0 : l.sq);
+    if (l.prev == 1 && l.player == 1) { // :192-197: W, W, B, W, W, B ...
+        l.player = 2;
+        l.prev = 1;
+    } else {
+        l.prev = l.player;
+        l.player = 1;
+    }
+    const int b4 = __builtin_amdgcn_readlane(l.sq, 4), b7 = __builtin_amdgcn_readlane(l.sq, 7), b0 = __builtin_amdgcn_readlane(l.sq, 0);
+    const int b60 = __builtin_amdgcn_readlane(l.sq, 60), b63 = __builtin_amdgcn_readlane(l.sq, 63), b56 = __builtin_amdgcn_readlane(l.sq, 56);
+    int c = l.castle; // :199-212
+    if (b4 != 1) c &= ~3;
+    else if (b7 != 5) c &= ~1;
+    if (b0 != 5) c &= ~2;
+    if (b60 != -1) c &= ~12;
+    else if (b63 != -5) c &= ~4;
+    if (b56 != -5) c &= ~8;
+    l.castle = c;
+    const bool bk = __ballot(l.sq == -1) != 0, wk = __ballot(l.sq == 1) != 0;
+    return !bk ? 1 : (!wk ? 2 : -1);
+}
+
 // AddChildren for the node `node` (state st): move generation (lane = from-square), priors, edge rows.
 // policy == nullptr and hl == nullptr -> MCTS.GetPriors default (ones).  lds: DC_LDS_FLOATS floats of scratch owned by this wave.
 // board_mem: the 64 board bytes of `st` in memory (one coalesced load instead of dynamic indexing into registers)
 // node_idx / node_flags / used: the node's index (== its serial), its flags before the expansion and the slot's edge
 // cursor, loaded by the caller along with its other first-round loads (used is advanced on success).
-__device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *node, const DCState &st,
+__device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *node, const int st_player,
                           const int8_t *board_mem, const float *policy, const DCHeadLocal *hl, uint32_t gid, int lane,
                           float *lds, int node_idx, int node_flags, int &used) {
     const bool priors = policy != nullptr || hl != nullptr; // evaluator priors (dense row in memory, or the compact head)
@@ -173,7 +228,7 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
     // move generation: lane = from-square; occupancy by two ballots, targets by bit operations (games.hip.h)
     const int piece = board_mem[lane];
     const uint64_t white = __ballot(piece > 0), black = __ballot(piece < 0);
-    uint64_t m = DragonChess::targets_bits(piece, st.player, lane, white, black);
+    uint64_t m = DragonChess::targets_bits(piece, st_player, lane, white, black);
     int cnt = bb_popc64(m);
     int pre = wave_excl_scan_i(cnt, lane);
     int total = wave_sum_i(cnt);
@@ -290,7 +345,8 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
 #endif
     DCNode *pool = (DCNode *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     DCNode *node = pool + leaf;
-    DCState st = ((const DCState *)d.leaf_state)[g];
+    const DCState *leaf_st = (const DCState *)d.leaf_state + g;
+    const int st_player = leaf_st->player, st_prev = leaf_st->prev;
     // the path's statistics (edges and nodes above the leaf: the expansion below touches none of them)
     const bool on_path = lane < plen;
     DCNode *my_nd = pool + (on_path ? pn0 : 0u);
@@ -313,11 +369,11 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
 #endif
     if (pend_exp) {
         uint32_t gid = d.first_game_id + (uint32_t)lid;
-        if (!dc_expand(d, E, g, node, st, ((const DCState *)d.leaf_state)[g].b, hl ? nullptr : d.eval_policy + (size_t)g * 4032, hl, gid,
+        if (!dc_expand(d, E, g, node, st_player, leaf_st->b, hl ? nullptr : d.eval_policy + (size_t)g * 4032, hl, gid,
                        lane, lds, leaf, leaf_flags, used) && lane == 0)
             d.ctr[(size_t)g * 8 + 6] += 1;
     }
-    int player = st.player, prev = st.prev;
+    int player = st_player, prev = st_prev;
     float v01;
     if (d.evaluator == 2) {
         v01 = v;
@@ -420,7 +476,7 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
     int depth = 0, expand = 0, overflow = 0, term_leaf = 0;
     const bool inline_expand = d.priors_ones != 0;
     const bool fixed = d.kind == 1, rollout = d.evaluator == 2;
-    DCState st;
+    DCLane st = {0, 0, 0, 0}; // the leaf's position, one square per lane
     int flags = 0;
     bool have = false;
     uint32_t my_pn = 0, my_pe = 0;
@@ -440,14 +496,14 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
         bool have_st = have;
         have = false;
         if (fixed && it >= d.max_depth) {
-            if (!have_st) st = node->st;
+            if (!have_st) st = dc_lane_load(&node->st, lane);
             break;
         }
         if (!(flags & NODE_EXPANDED)) {
-            if (!have_st) st = node->st;
+            if (!have_st) st = dc_lane_load(&node->st, lane);
             if (flags & NODE_TERMINAL) { term_leaf = 1; break; }
             if (!inline_expand) { expand = 1; break; }
-            if (!dc_expand(d, E, g, node, st, node->st.b, nullptr, nullptr, 0u, lane, lds, cur, flags, used)) { overflow = 1; break; }
+            if (!dc_expand(d, E, g, node, st.player, node->st.b, nullptr, nullptr, 0u, lane, lds, cur, flags, used)) { overflow = 1; break; }
             __threadfence_block();
             if (!fixed) break;
             n_edges = node->n_edges;
@@ -455,7 +511,7 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
             sq = 1.0;
         }
         if (n_edges == 0) {
-            if (!have_st) st = node->st;
+            if (!have_st) st = dc_lane_load(&node->st, lane);
             break;
         }
         // PUCT over the node's edges, 64 per pass
@@ -483,7 +539,7 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
         }
         wave_argmax(bu, bi, bchild, bact);
         QS(q_cmp);
-        if (depth >= DragonChess::MAXPATH) { overflow = 1; if (!have_st) st = node->st; break; }
+        if (depth >= DragonChess::MAXPATH) { overflow = 1; if (!have_st) st = dc_lane_load(&node->st, lane); break; }
         int child = bchild;
         { // the path stays in registers (lane k <-> depth k) until the descent is over: a store per level would put
           // a write acknowledgement in front of every following load (vmcnt counts both, in order)
@@ -498,13 +554,27 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
                 pe[depth] = pev;
             }
         }
-        if (child == CHILD_NONE) {
-            DCState pst = node->st, st2;
-            bool terminal;
-            child = dc_create_child(d, E, g, pool, pst, bact, base + bi, lane, nn, st2, terminal);
-            if (child == CHILD_NONE) { overflow = 1; st = pst; break; }
-            st = st2;
-            flags = (terminal ? NODE_TERMINAL : 0) | ((int)st2.player << 4);
+        if (child == CHILD_NONE) { // materialise the child: _applyAction on the parent's position, Winner(lastAction)
+            st = dc_lane_load(&node->st, lane);
+            if (nn >= d.node_cap) { overflow = 1; break; } // pool exhausted: the parent's position stands in as the leaf
+            const int w = dc_lane_apply(st, bact, lane);
+            const bool terminal = w >= 0;
+            const int idx = nn++;
+            child = idx | (terminal ? CHILD_TERM_BIT : 0);
+            {
+                DCNode *c = pool + idx;
+                dc_lane_store(&c->st, st, lane);
+                if (lane == 0) {
+                    c->flags = (terminal ? (NODE_TERMINAL | ((w + 1) << 8)) : 0) | (st.player << 4);
+                    c->n_edges = 0;
+                    c->edge_off = 0;
+                    c->all = 0;
+                    c->serial = idx;
+                    E.e[base + bi].child = child;
+                    // (n_nodes[g] and the node counter are written once by the tail: nn carries the new count)
+                }
+            }
+            flags = (terminal ? NODE_TERMINAL : 0) | (st.player << 4);
             have = true;
             __threadfence_block();
             if (!inline_expand && !fixed) { // the node just created is this descent's leaf: no need to go round once more to read it back
@@ -522,8 +592,8 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
         pn[lane] = my_pn;
         pe[lane] = my_pe;
     }
+    dc_lane_store((DCState *)d.leaf_state + g, st, lane);
     if (lane == 0) {
-        ((DCState *)d.leaf_state)[g] = st;
         d.leaf_game_id[g] = d.first_game_id + (uint32_t)lid;
         d.leaf_serial[g] = cur;
         d.pend_leaf[g] = cur;
