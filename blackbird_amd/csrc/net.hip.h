@@ -390,17 +390,44 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
         const f32x4 bias = bias0, scale = scale0, shift = shift0;
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = bias;
-#pragma unroll
-        for (int s = 0; s < STEPS0; s++) {
+        auto step_toff = [&](int s) __attribute__((always_inline)) {
             int k = 4 * s + j;
             int kk = k < 9 * CIN ? k : 9 * CIN - 1; // padded k: weight is 0, any readable address will do
             int tap = kk / CIN, c = kk % CIN;
-            int toff = ((tap / 3) * (W + 1) + (tap % 3)) * CP + c;
-            float a = w0r[s];
+            return ((tap / 3) * (W + 1) + (tap % 3)) * CP + c;
+        };
+        if constexpr (WMODE == 1 && NT <= 6) {
+            // a lone wave per SIMD: the pixel operands of k-step s + 1 are requested before the MFMAs of step s are issued
+            float b[NT], bn[NT];
+            {
+                const int toff = step_toff(0);
 #pragma unroll
-            for (int t = 0; t < NT; t++) {
-                float b = inp[ioffb[t] + toff];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; t++) b[t] = inp[ioffb[t] + toff];
+            }
+#pragma unroll
+            for (int s = 0; s < STEPS0; s++) {
+                if (s + 1 < STEPS0) {
+                    const int toffn = step_toff(s + 1);
+#pragma unroll
+                    for (int t = 0; t < NT; t++) bn[t] = inp[ioffb[t] + toffn];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[s], b[t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) b[t] = bn[t];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < STEPS0; s++) {
+                const int toff = step_toff(s);
+                float a = w0r[s];
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    float b = inp[ioffb[t] + toff];
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
