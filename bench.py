@@ -287,7 +287,9 @@ def main():
     first_tot = rec_all["total"][offs_all[fin]] if len(fin) else np.zeros(0)
     full = fin[first_tot >= sims - 1] if len(fin) else fin
     mean_plies_all = float((lens[fin] - 1).mean()) if len(fin) else 0.0
-    mean_plies_full = float((lens[full] - 1).mean()) if len(full) else 0.0
+    # games that started at full strength AND finished inside a short run are the short ones: only trust their mean when
+    # the run is long enough for typical games to be among them
+    mean_plies_full = float((lens[full] - 1).mean()) if (len(full) >= 200 and total_plies - prefill >= w["max_plies"]) else 0.0
     if dist is not None:
         dev = f"cuda:{local}" if backend == "nccl" else None
         (games, nsims, plies), (dt,) = bdist.reduce_totals([games, nsims, plies], [dt], device=dev)
@@ -331,7 +333,9 @@ def main():
         b_sim = tree_bytes_per_sim(w, mean_depth, a_c)
         tree_gbps = b_sim * sims_per_launch / (net_ms * 1e-3) / 1e9 if net_ms > 0 else 0.0
         traffic_rate, traffic_src = pmc_traffic_bytes_per_second(args.workload)
-        mean_len = mean_plies_full or mean_plies_all
+        # mean game length for the steady-state estimate and the CPU extrapolation: observed, or (no game finished in this
+        # run) the value default runs of that workload observe
+        mean_len = mean_plies_full or mean_plies_all or {"c2": 28.0, "c5": 28.0, "dc": 60.0}[args.workload]
         out = {
             "metric": "selfplay_games_per_sec", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / max(K, 1) * 1e3,
@@ -350,7 +354,7 @@ def main():
             "plies_per_step": plies / max(K, 1) / (slots * world),
             "games_finished": games, "mean_plies_finished_games": mean_plies_all,
             "mean_plies_games_started_at_full_sims": mean_plies_full,
-            "games_per_sec_steady": (plies / dt) / mean_len if mean_len > 0 else None,
+            "games_per_sec_steady": (plies / dt) / mean_len if mean_len > 0 else None, "mean_plies_used": mean_len,
             "examples_fetched": int(len(rec_t)), "examples_fetch_s": fetch_s,
             "terminal_leaf_fraction": cnt["terminal_leaves"] / max(cnt["sims"], 1),
             "mean_leaf_depth": mean_depth, "overflow": cnt["overflow"],
