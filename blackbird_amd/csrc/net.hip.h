@@ -308,15 +308,24 @@ __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0,
 // engine slot slot_list[i] (inputs are read from, and outputs written to, that slot's mailbox).
 // WMODE: how the tower's operands reach the MFMAs (see conv_layer below): 0 plain, 1 weights from L2 with next-layer
 // prefetch, 2 weights in LDS with next-tap prefetch.
-template <class G, int PW, int WMODE = 0>
+// Team: the evaluation may be shared by PARTS waves working in the SAME LDS region (mega_dc.hip.h: two waves of a
+// DragonChess game on two SIMDs): every wave takes NT / PARTS of the 16-pixel tiles of each conv layer, part 0 alone does the
+// prologue (zero fill, input planes) and the heads, and `team.sync()` is called wherever one part's LDS writes are another
+// part's reads: after the prologue and after every conv layer.  The default team is the wave on its own.
+struct SoloTeam {
+    static constexpr int PARTS = 1, PART = 0;
+    __device__ __forceinline__ void sync() const {}
+};
+template <class G, int PW, int WMODE = 0, class Team = SoloTeam>
 __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, const int *slot_list, float *wlds,
                                          const typename G::State *states, const int8_t *planes,
                                          const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
                                          float *logits_out, float *policy_out, int pstride, bool zero_lds = true,
-                                         WideHead *compact = nullptr) {
+                                         WideHead *compact = nullptr, Team team = Team()) {
     using NG = NetGeom<G, PW>;
+    static_assert(NG::NT % Team::PARTS == 0, "whole tiles per team member");
     constexpr int W = NG::W, CIN = NG::CIN, A = NG::A, HW = NG::HW, SLOTS = NG::SLOTS, CP = NG::CP,
-                  NT = NG::NT, STEPS0 = NG::STEPS0, ACT = NG::ACT, PLANE = NG::PLANE;
+                  NT = NG::NT / Team::PARTS, T0 = Team::PART * NT, STEPS0 = NG::STEPS0, ACT = NG::ACT, PLANE = NG::PLANE;
     const int lane = threadIdx.x & 63;
     const int j = lane >> 4, nn = lane & 15;
     float *actA = wlds;
@@ -337,7 +346,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
     const f32x4 bias0 = *(const f32x4 *)(nd.epi + 4 * j), scale0 = *(const f32x4 *)(nd.epi + 16 + 4 * j),
                 shift0 = *(const f32x4 *)(nd.epi + 32 + 4 * j);
     // ---- zero this wave's LDS (halo pixels must read as 0 forever) --------------------------
-    if (zero_lds) { // a persistent caller zeroes once: halos are never written, interiors are always rewritten
+    if (zero_lds && Team::PART == 0) { // a persistent caller zeroes once: halos are never written, interiors are always rewritten
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         f32x4 *p = (f32x4 *)actA;
         for (int i = lane; i < NG::WAVE_FLOATS / 4; i += 64) p[i] = z;
@@ -345,10 +354,10 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
     // the PW boards go through LDS so that every lane can decode any cell of any position
     typename G::State *sst = (typename G::State *)(inp + PW * SLOTS * CP);
     wave_lds_handover(); // (the zero fill above and the data written below touch the same words from different lanes)
-    if (!planes && lane < PW) sst[lane] = my_state;
+    if (!planes && lane < PW && Team::PART == 0) sst[lane] = my_state;
     wave_lds_handover();
     // ---- input planes -> inp[pos][slot][CP] ---------------------------------------------------
-    for (int q = lane; q < PW * HW; q += 64) {
+    for (int q = lane; Team::PART == 0 && q < PW * HW; q += 64) {
         int pp = q / HW, cell = q % HW, y = cell / W, x = cell % W;
         int pos = pos0 + pp;
         if (pos >= n) continue;
@@ -375,7 +384,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
     int ioffb[NT];  // float offset of (pos, slot - TAP0) inside inp
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        int q = t * 16 + nn;
+        int q = (T0 + t) * 16 + nn;
         int qq = q < PW * HW ? q : PW * HW - 1;
         int pp = qq / HW, cell = qq % HW, y = cell / W, x = cell % W;
         int slot = (y + 1) * (W + 1) + (x + 1);
@@ -383,6 +392,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
         ioffb[t] = (pp * SLOTS + slot - TAP0) * CP;
     }
     wave_lds_handover(); // input planes (and the staged boards) written above are read by other lanes below
+    team.sync();
     NSTAMP(0);
     f32x4 acc[NT];
     // ---- first conv: K = 9*CIN in natural (tap, c) order, 4 k per MFMA ---------------------------
@@ -439,6 +449,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
         }
     }
     wave_lds_handover();
+    team.sync();
     NSTAMP(1);
     // ---- residual tower: 2R convs, K order (tap, r, j) with channel c = 4j + r ---------------------
     // One layer = 9 taps x 4 k-steps x NT tiles of MFMAs + the epilogue; written once (conv_layer) and instantiated for
@@ -581,11 +592,13 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
             *(f32x4 *)(out + aoffb[t] + CTR) = y;
         }
         wave_lds_handover(); // this layer's pixels are the next layer's (and the heads') operands, across lanes
+        team.sync();
     };
     for (int blk = 0; blk < R_eff; blk++) {
         conv_layer(2 * blk, actA, actB, std::false_type{});
         conv_layer(2 * blk + 1, actB, actA, std::true_type{});
     }
+    if constexpr (Team::PART != 0) return; // the heads are part 0's
     if (nd.dbg & 1) {
         if (value_out && lane == 0) value_out[OI(pos0)] = acc[0][0];
         return;

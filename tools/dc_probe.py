@@ -2,6 +2,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from blackbird_amd import _lib, weights as W
+if os.environ.get("BB_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["BB_LIB"])
 game = _lib.GAME_DRAGONCHESS
 t = time.time()
 eng = _lib.Engine(game, n_slots=1024, sims_per_move=400, evaluator=_lib.EVAL_NET, noise_on=True, max_games=2048, max_plies=int(os.environ.get("DC_MAX_PLIES","512")))
