@@ -1192,13 +1192,8 @@ extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
                     const int now = plies - done < 16 ? plies - done : 16;
                     bool timed = e->time_every > 0 && e->ev_used + 2 <= e->ev_pool.size();
                     if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
-                    const bool pair = !(getenv("BB_DC_PAIR") && atoi(getenv("BB_DC_PAIR")) == 0); // two waves per game (default) / one
-                    if (pair)
-                        k_dc_selfplay_pair<<<(e->dev.n_slots + 3) / 4, 512, 0, e->stream>>>(e->dev, e->edges, e->net, now, e->sims_now,
-                                                                                            getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30);
-                    else
-                        k_dc_selfplay_fused<<<nblk((size_t)e->dev.n_slots * 64), 256, 0, e->stream>>>(e->dev, e->edges, e->net, now, e->sims_now,
-                                                                                                      e->cfg.noise_on);
+                    k_dc_selfplay_fused<<<nblk((size_t)e->dev.n_slots * 64), 256, 0, e->stream>>>(e->dev, e->edges, e->net, now, e->sims_now,
+                                                                                                  e->cfg.noise_on);
                     HIPCHK(hipGetLastError());
                     if (timed) {
                         HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
