@@ -67,11 +67,97 @@ def _records_to_examples(game_cls, rec):
     return out
 
 
+def _timed_selfplay(model, nGames, temp):
+    """GenerateTrainingSamples when the searcher has a wall-clock limit per move (mcts.timeLimit, MCTS.py:173-182, :298):
+    the reference's loop (FindMove, example, MoveRoot, Winner) for all games of a wave at once through the lock-step entry
+    points -- every move, all live games are searched together until `TimeLimit` seconds have passed (and no further than
+    PlayLimit simulations when that is set too), then each samples its move with numpy's next uniform."""
+    from time import time
+    game_cls = model.Game
+    game = game_cls.GAME_ID
+    gi = _lib.game_info(game)
+    max_plies = {_lib.GAME_CONNECT4: 42, _lib.GAME_TICTACTOE: 9}.get(game, 512)
+    cap = model._MAX_NODES
+    n_slots, _ = _lib.fit_slots(game, min(nGames, MAX_CONCURRENT_GAMES), 64, node_capacity=cap)
+    eng = model._make_engine(game, n_slots, 64, node_capacity=cap)
+    model._after_engine_created(eng)
+    eng.set_rng_stream(int(np.random.randint(0, 2 ** 62, dtype=np.int64)), model._games_played)
+    try:
+        for first in range(0, nGames, n_slots):
+            n = min(n_slots, nGames - first)
+            idx = np.arange(n)
+            states = np.repeat(_lib.game_initial(game), n, axis=0)
+            eng.set_roots(states, slots=idx, game_ids=model._games_played + first + idx)
+            alive = np.ones(n_slots, dtype=bool)
+            alive[n:] = False
+            history = [[] for _ in range(n)]       # per game: (planes, pi, player)
+            winner = np.full(n, -1)
+            for _ply in range(max_plies):
+                live = np.nonzero(alive)[0]
+                if not len(live):
+                    break
+                end, done = time() + model.TimeLimit, 0
+                while True:                        # _runMCTS: at least one chunk, so that every root is expanded
+                    eng.run_sims(16, mask=alive)
+                    eng.synchronize()
+                    done += 16
+                    if time() >= end or (model.PlayLimit is not None and done >= model.PlayLimit):
+                        break
+                if eng.counters()['overflow']:
+                    raise _lib.BlackbirdHipError('search tree outgrew the node pool')
+                u = np.zeros(n_slots)
+                u[live] = np.random.random_sample(len(live))
+                out = eng.sample_moves(temp, u if temp != 0 else None)
+                planes = _lib.game_encode(game, states[live])
+                acts = np.full(n_slots, -1, dtype=np.int32)
+                for k, gidx in enumerate(live):
+                    if out['action'][gidx] < 0:
+                        raise ValueError('probabilities contain NaN')
+                    plays = out['child_plays'][gidx].astype(np.float64)
+                    pi = np.zeros(gi.A)
+                    if gi.dense:
+                        pi[:] = plays[:gi.A]
+                    else:
+                        nch = int((out['child_action'][gidx] >= 0).sum())
+                        pi[out['child_action'][gidx][:nch]] = plays[:nch]
+                    pi /= pi.sum()
+                    history[gidx].append((planes[k:k + 1], pi, _side_to_move(game, states[gidx])))
+                    acts[gidx] = out['action'][gidx]
+                states[live], status = _lib.game_apply(game, states[live], acts[live])
+                if (status != 0).any():
+                    raise ValueError('Tried to make an illegal move.')
+                eng.move_roots(acts)
+                w = _lib.game_winner(game, states[live])       # state.Winner(): full scan (Blackbird.py:253)
+                for k, gidx in enumerate(live):
+                    if w[k] >= 0:
+                        winner[gidx] = int(w[k])
+                        alive[gidx] = False
+            final_planes = _lib.game_encode(game, states[:n])
+            for gidx in range(n):                  # terminal example, z, one PutGames per game (Blackbird.py:256-268)
+                ex = history[gidx] + [(final_planes[gidx:gidx + 1], np.zeros(gi.A), _side_to_move(game, states[gidx]))]
+                wn = winner[gidx]
+                blobs = [ExampleState(0 if wn <= 0 else (1 if pl == wn else -1), pi, pln, player=pl).SerializeState()
+                         for pln, pi, pl in ex]
+                model.Conn.PutGames(model.Name, model.Version, game_cls.GameType, blobs)
+    finally:
+        eng.close()
+    model._games_played = (model._games_played + nGames) % (1 << 31)
+
+
+def _side_to_move(game, packed):
+    """Player of one packed state (include/blackbird_hip.h layouts)."""
+    if game == _lib.GAME_DRAGONCHESS:
+        return int(np.asarray(packed).view(np.uint8).reshape(-1)[64])
+    return int((int(np.asarray(packed).view(np.uint64).reshape(-1)[0]) >> 56) & 3)
+
+
 def GenerateTrainingSamples(model, nGames, temp):
     """Blackbird.py:219-268.  Raises ValueError if nGames <= 0."""
     if nGames <= 0:
         raise ValueError('Use a positive integer for number of games.')
     game_cls = model.Game
+    if model.TimeLimit is not None:
+        return _timed_selfplay(model, nGames, temp)
     eng = model._selfplay_engine(nGames)
     # every call is a fresh draw, as in the reference (new numpy choices and new graph noise each time): a new Philox
     # key from numpy's generator (advancing it) and game ids that continue where the model's last run stopped
@@ -235,7 +321,7 @@ class Model(MCTS, Network):
         at MAX_CONCURRENT_GAMES and at what the device's free memory holds (DragonChess pools are sized for 512 plies x
         PlayLimit nodes with 24 edges each: ~0.16 GB per slot at 400 simulations); further games queue on the slots."""
         if self.PlayLimit is None:
-            raise ValueError('Not enough information to decide a stop time.')  # (a wall-clock limit has no batched meaning)
+            raise ValueError('Not enough information to decide a stop time.')  # (MCTS.py:181-182; a time limit takes _timed_selfplay)
         want = min(n_games, MAX_CONCURRENT_GAMES)
         eng = self._batch_engine
         if eng is not None and (eng.cfg.max_games < n_games or getattr(eng, '_want', 0) < want or eng.cfg.sims_per_move != int(self.PlayLimit)):

@@ -130,3 +130,43 @@ def test_capacity_is_reported_not_crashed():
     # and a slot that cannot exist at all is BB_ERR_CAPACITY too
     with pytest.raises(_lib.BlackbirdHipError, match="not even one"):
         _lib.fit_slots(game, 4, 400, max_games=1 << 20)  # a 0.5 TB example store
+
+
+def test_time_limited_batched_selfplay(tmp_path, monkeypatch):
+    """mcts.timeLimit without playLimit (MCTS.py:173-182): every move all games are searched together for the budget; the
+    examples are the reference's: per ply (planes, visit distribution over legal moves, side to move), a terminal example with
+    pi = 0, z by the winner, one PutGames per game."""
+    monkeypatch.chdir(tmp_path)
+    from blackbird_amd import TicTacToe, proto_wire
+    model = Blackbird.Model(TicTacToe.BoardState, "timed", {"explorationRate": 0.85, "timeLimit": 0.02}, dict(CFG, blocks=1))
+    assert model.PlayLimit is None
+    np.random.seed(5)
+    Blackbird.GenerateTrainingSamples(model, 5, 1.0)
+    blobs = model.Conn.GetGames(model.Name, model.Version)
+    exs = [Blackbird.ExampleState.FromSerialized(b) for b in blobs]
+    terminal = [e for e in exs if not e.MctsPolicy.any()]
+    assert len(terminal) == 5 and 5 * 6 <= len(exs) <= 5 * 10
+    for e in exs:
+        assert e.Board.shape == (1, 3, 3, 3) and e.MctsEval[0] in (-1.0, 0.0, 1.0)
+        if e.MctsPolicy.any():
+            assert abs(e.MctsPolicy.sum() - 1.0) < 1e-12
+            empty = (e.Board[0, :, :, 0] == 0) & (e.Board[0, :, :, 1] == 0)
+            assert (e.MctsPolicy.reshape(3, 3)[~empty] == 0).all()   # visits only on legal (empty) cells
+    assert model._games_played == 5
+    model.Conn.Close()
+
+
+def test_dragonchess_getpolicy_mixes_noise():
+    """Network.getPolicy for the wide game must mix the graph's Beta noise like the other games do."""
+    game = _lib.GAME_DRAGONCHESS
+    eng = _lib.Engine(game, n_slots=2, sims_per_move=2, evaluator=_lib.EVAL_NET, alpha=0.2, epsilon=0.3, seed=4, max_plies=8)
+    eng.load_weights(W.flatten(W.init_weights(17, 16, 1, 16, 4032, seed=1)))
+    st = _lib.game_initial(game)
+    clean = eng.net_eval(states=st)[2][0].astype(np.float64)
+    n1 = eng.net_eval(states=st, noise=1)[2][0].astype(np.float64)
+    n2 = eng.net_eval(states=st, noise=2)[2][0].astype(np.float64)
+    assert abs(clean.sum() - 1) < 1e-4 and abs(n1.sum() - 1) < 1e-4 and not np.array_equal(n1, n2)
+    # undo the mix: q = (1-eps) p + eps x, noisy = q / sum(q); the x are Beta(0.2, 0.8) draws: mean 0.2, in (0, 1)
+    x = (n1 * ((1 - 0.3) + 0.3 * 4032 * 0.2) - 0.7 * clean) / 0.3        # with sum(q) ~ 0.7 + 0.3 * A * alpha
+    assert 0.15 < x.mean() < 0.25 and (x > -0.05).all()
+    eng.close()
