@@ -22,6 +22,12 @@
 
 #define MEGA2_THREADS 768 // 12 waves: NETW network waves + (12 - NETW) tree waves
 #define MEGA2_QCAP 32
+#ifndef BB_TREE_IDLE_SLEEP
+#define BB_TREE_IDLE_SLEEP 4 // s_sleep argument (x 64 cycles) of a tree wave that finds none of its games ready
+#endif
+#ifndef BB_NET_IDLE_SLEEP
+#define BB_NET_IDLE_SLEEP 4  // ... of a network wave that finds the queue empty
+#endif
 #ifndef BB_NET_APPLIES
 #define BB_NET_APPLIES 1 // the network wave that evaluated a leaf also expands it and backs its value up (phase_apply), see below
 #endif
@@ -224,7 +230,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
                 t_work += clock64() - ts;
 #endif
             } else {
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(BB_TREE_IDLE_SLEEP);
                 int late = wall_clock64() - t_start > t_limit || lds_load(&qc.abort_flag);
                 if (__builtin_amdgcn_readfirstlane(late)) {
                     qc.abort_flag = 1;
@@ -255,7 +261,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
             const int li = __builtin_amdgcn_readfirstlane(queue_pop(&qc, t_start, t_limit, TREEW)); // scalar: uniform branches below
             if (li == -2) break;
             if (li < 0) {
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(BB_NET_IDLE_SLEEP);
                 continue;
             }
             __threadfence_block(); // acquire: the tree wave's mailbox writes
