@@ -72,40 +72,58 @@ struct DCHeadLocal {
 };
 
 // ---- wave (64 lanes) collectives ----------------------------------------------------------------------
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Inclusive prefix sum over the 64 lanes in DPP moves only (the scan LLVM's atomic optimiser builds): row_shr 1, 2, 4, 8 inside
+// the rows of 16 (lanes without a source add 0), then row_bcast:15 into rows 1 / 3 and row_bcast:31 into rows 2 / 3.
+__device__ __forceinline__ int wave_incl_scan_i(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
     return v;
 }
-__device__ __forceinline__ int wave_excl_scan_i(int v, int lane) {
-    int x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int y = __shfl_up(x, o, 64);
-        if (lane >= o) x += y;
-    }
-    return x - v;
-}
+__device__ __forceinline__ int wave_sum_i(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_i(v), 63); }
+__device__ __forceinline__ int wave_excl_scan_i(int v, int /*lane*/) { return wave_incl_scan_i(v) - v; }
 // first maximum (lowest idx on ties); idx < 0 marks "no candidate".  Two stages instead of a six-step butterfly over
 // (value, index, two payloads) -- 30 cross-lane reads: the wave maximum of the score (DPP inside the rows of 16, two
 // ds_bpermute steps across rows), the smallest index among the lanes that hold it, then two v_readlane for the payloads.
+// Wave-wide max / min without the LDS crossbar: butterflies inside the rows of 16 (quad_perm, row_half_mirror, row_mirror: every
+// lane of a row ends with the row's result), then the gfx9 DPP row broadcasts -- row_bcast:15 hands lane 15 of rows 0 / 2 to
+// rows 1 / 3, row_bcast:31 hands lane 31 to rows 2 and 3 -- leave the wave's result in row 3, and one v_readlane of lane 63
+// makes it a scalar.  (The two cross-row steps were ds_bpermute round trips before: ~250 cycles per reduction for a lone wave,
+// two reductions per tree level.)
+__device__ __forceinline__ int dpp_bcast15_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false); }
+__device__ __forceinline__ int dpp_bcast31_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false); }
+__device__ __forceinline__ double dpp_bcast15_d(double v) {
+    long long b = __double_as_longlong(v);
+    int lo = dpp_bcast15_i((int)(b & 0xffffffffll)), hi = dpp_bcast15_i((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double dpp_bcast31_d(double v) {
+    long long b = __double_as_longlong(v);
+    int lo = dpp_bcast31_i((int)(b & 0xffffffffll)), hi = dpp_bcast31_i((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_max_f64(double v) {
     v = __builtin_fmax(v, dpp_step_d<0>(v));
     v = __builtin_fmax(v, dpp_step_d<1>(v));
     v = __builtin_fmax(v, dpp_step_d<2>(v));
     v = __builtin_fmax(v, dpp_step_d<3>(v));
-    v = __builtin_fmax(v, __shfl_xor(v, 16, 64));
-    v = __builtin_fmax(v, __shfl_xor(v, 32, 64));
-    return v;
+    v = __builtin_fmax(v, dpp_bcast15_d(v));
+    v = __builtin_fmax(v, dpp_bcast31_d(v));
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
     v = min(v, dpp_step_i<0>(v));
     v = min(v, dpp_step_i<1>(v));
     v = min(v, dpp_step_i<2>(v));
     v = min(v, dpp_step_i<3>(v));
-    v = min(v, __shfl_xor(v, 16, 64));
-    v = min(v, __shfl_xor(v, 32, 64));
-    return v;
+    v = min(v, dpp_bcast15_i(v));
+    v = min(v, dpp_bcast31_i(v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ void wave_argmax(double &u, int &idx, int &p0, int &p1) {
     const double m = wave_max_f64(idx >= 0 ? u : -2.0); // PUCT scores are >= -1
