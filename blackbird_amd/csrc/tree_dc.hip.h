@@ -55,11 +55,11 @@ struct DCEdges { // per-slot edge pool, stride edge_cap
 // diagnostic build: cycle stamps accumulate in the wave's LDS scratch (16 words past the policy image) and are flushed
 // once when the kernel ends, spread over 64 copies -- atomics inside the timed sections would sit in front of every
 // later s_waitcnt and a thousand waves on one address serialise in L2
-#define DC_STAMP_OFF 4768 // past the policy image AND past the network's activations, which share the scratch in mega_dc.hip.h
+#define DC_STAMP_OFF 4768 // past the policy image and its 112 floats of sum scratch AND past the network's activations, which share the scratch in mega_dc.hip.h
 #define DC_LDS_FLOATS (DC_STAMP_OFF + 32)
 #define DST(i, v) do { if (lane == 0) ((unsigned long long *)(lds + DC_STAMP_OFF))[i] += (unsigned long long)(v); } while (0)
 #else
-#define DC_LDS_FLOATS 4032
+#define DC_LDS_FLOATS (4032 + 112) // the policy image + dc_np_sum's scratch (8 + 48 doubles)
 #define DST(i, v) do {} while (0)
 #endif
 
@@ -144,24 +144,54 @@ __device__ __forceinline__ void wave_argmax(double &u, int &idx, int &p0, int &p
 // numpy pairwise add.reduce over the dense image a[4032] in LDS (float32 values, summed as float64).  numpy's recursion
 // (n > 128: n2 = n/2 rounded down to a multiple of 8; pairwise(a, n2) + pairwise(a+n2, n-n2)) cuts 4032
 // into 16 runs of 252 = leaf(120) + (leaf(64) + leaf(68)); a leaf keeps 8 strided partials, folds them
-// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and adds its tail sequentially.  Lane 3*run+part sums one leaf.
-__device__ __forceinline__ double dc_np_sum(const float *a, int lane) {
-    double res = 0.0;
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and adds its tail sequentially.
+//
+// A position has a few dozen legal moves, so most of the 48 leaves hold nothing but zeros and sum to exactly 0.0.  `leaves`
+// = bit L set for every leaf that holds a nonzero (uniform; the caller ORs it together from its moves).  Only those are
+// summed, EIGHT LANES PER LEAF -- lane j of a group owns partial r_j, 15 (or 8) sequential adds instead of one lane's
+// 120 -- eight leaves per round; the fold of the partials is the xor butterfly 1, 2, 4 inside the group, which is exactly
+// the bracket above.  `scr`: 8 + 48 doubles of scratch (leaf list, leaf sums).
+__device__ __forceinline__ int dc_leaf_of(int a) { // leaf index 3 * run + part of action id a
+    const int run = a / 252, pos = a - run * 252;
+    return 3 * run + (pos >= 184 ? 2 : (pos >= 120 ? 1 : 0));
+}
+__device__ __forceinline__ double dc_np_sum(const float *a, unsigned long long leaves, double *scr, int lane) {
+    unsigned char *list = (unsigned char *)scr; // [48] indices of the non-empty leaves, ascending
+    double *leafsum = scr + 8;                 // [48]
     if (lane < 48) {
-        int run = lane / 3, part = lane % 3;
-        int off = run * 252 + (part == 0 ? 0 : part == 1 ? 120 : 184);
-        int len = part == 0 ? 120 : part == 1 ? 64 : 68;
-        const float *b = a + off; // (double)float is exact: the image holds the float32 policy values the reference multiplies by its float64 mask
-        double r[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) r[j] = (double)b[j];
-        int i = 8;
-        for (; i < len - (len % 8); i += 8)
-#pragma unroll
-            for (int j = 0; j < 8; j++) r[j] += (double)b[i + j];
-        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < len; i++) res += (double)b[i];
+        leafsum[lane] = 0.0;
+        if ((leaves >> lane) & 1ull) list[bb_popc64(leaves & ((1ull << lane) - 1ull))] = (unsigned char)lane;
     }
+    __threadfence_block();
+    const int n_leaves = bb_popc64(leaves);
+    const int grp = lane >> 3, j = lane & 7;
+    for (int base = 0; base < n_leaves; base += 8) { // (uniform trip count)
+        const bool on = base + grp < n_leaves;
+        const int L = on ? (int)list[base + grp] : 0;
+        const int run = L / 3, part = L - 3 * run;
+        const int off = run * 252 + (part == 0 ? 0 : part == 1 ? 120 : 184);
+        const int steps = part == 0 ? 15 : 8; // main part: 120 / 8 or 64 / 8 strided elements per partial
+        const float *b = a + off + j;
+        double r = 0.0; // (0.0 + x == x: starting from zero is starting from the first element)
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) r += (double)b[8 * i];
+            if (steps == 15) {
+#pragma unroll
+                for (int i = 8; i < 15; i++) r += (double)b[8 * i];
+            }
+        }
+        r += dpp_step_d<0>(r); // (r0+r1) ...                                  quad_perm [1,0,3,2]
+        r += dpp_step_d<1>(r); // ((r0+r1)+(r2+r3)) ...                        quad_perm [2,3,0,1]
+        r += dpp_step_d<2>(r); // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))          row_half_mirror: lane i <-> 7 - i of the group
+        if (on && j == 0) {
+            if (part == 2)     // leaf(68): the 4 elements past the 64 strided ones, in order
+                for (int i = 64; i < 68; i++) r += (double)a[off + i];
+            leafsum[L] = r;
+        }
+    }
+    __threadfence_block();
+    double res = lane < 48 ? leafsum[lane] : 0.0;
     double nxt = __shfl_down(res, 1, 64);
     double r12 = res + nxt;                      // meaningful on part-1 lanes: leaf(64) + leaf(68)
     double nxt12 = __shfl_down(r12, 1, 64);
@@ -278,12 +308,18 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
     double tot = 1.0;
     float myp[MPL];
     if (priors) {
-        for (int i = lane; i < 4032; i += 64) lds[i] = 0.f;
+        {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            f32x4 *img = (f32x4 *)lds;
+            for (int i = lane; i < 4032 / 4; i += 64) img[i] = z;
+        }
         __threadfence_block();
+        unsigned long long leaves = 0ull; // which leaves of numpy's pairwise sum hold one of this lane's moves
 #pragma unroll
         for (int i = 0; i < MPL; i++) {
             myp[i] = 0.f;
             if (mya[i] >= 0) {
+                leaves |= 1ull << dc_leaf_of(mya[i]);
                 // getPolicy()[a]: from the dense row the network kernel wrote, or computed here from the compact head --
                 // the same operations on the same inputs, so the same bits (net.hip.h: wide_prob)
                 float p = hl ? wide_prob<64>(hl->h, hl->pdk[mya[i]], hl->pdk[4032 + mya[i]], hl->pdb[mya[i]]) : policy[mya[i]];
@@ -296,7 +332,16 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
 #ifdef BB_STAMPS
         e1 = clock64();
 #endif
-        tot = dc_np_sum(lds, lane);
+        __threadfence_block();
+        {   // OR the lanes' leaf bits together (DPP inside the rows, row broadcasts across them, lane 63 has the wave's)
+            unsigned lo = (unsigned)leaves, hi = (unsigned)(leaves >> 32);
+#define BB_OR_STEP(f) lo |= (unsigned)f((int)lo); hi |= (unsigned)f((int)hi);
+            BB_OR_STEP(dpp_step_i<0>) BB_OR_STEP(dpp_step_i<1>) BB_OR_STEP(dpp_step_i<2>) BB_OR_STEP(dpp_step_i<3>)
+            BB_OR_STEP(dpp_bcast15_i) BB_OR_STEP(dpp_bcast31_i)
+#undef BB_OR_STEP
+            leaves = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+        }
+        tot = dc_np_sum(lds, leaves, (double *)(lds + 4032), lane);
 #ifdef BB_STAMPS
         e2 = clock64();
 #endif
