@@ -369,8 +369,18 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
         } else {
             int8_t v[CIN];
             G::encode_cell(sst[pp], y, x, v);
+            if constexpr (CIN > 4) { // wide input (DragonChess: 17 planes): whole float4 stores (CP is a multiple of 4; the pad planes are 0)
 #pragma unroll
-            for (int c = 0; c < CIN; c++) dst[c] = (float)v[c];
+                for (int c4 = 0; c4 < CP / 4; c4++) {
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (4 * c4 + r < CIN) ? (float)v[4 * c4 + r] : 0.f;
+                    *(f32x4 *)(dst + 4 * c4) = o;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CIN; c++) dst[c] = (float)v[c];
+            }
         }
     }
     // ---- per-tile addressing: lane (j, nn) <-> pixel nn of the tile, channels 4j..4j+3 ---------
