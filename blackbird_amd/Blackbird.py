@@ -166,7 +166,7 @@ def GenerateTrainingSamples(model, nGames, temp):
     eng.reset_counters()
     eng.selfplay_begin(nGames, temp)
     while not eng.selfplay_done()[0]:
-        eng.selfplay_step(4)
+        eng.selfplay_step(8)  # (a persistent launch per call: few long launches beat many short ones, each has a tail)
         if eng.counters()['overflow']:  # pool exhausted, a parked slot or an aborted launch: the games would never finish
             raise _lib.BlackbirdHipError('self-play stopped: a search tree outgrew its node pool or a launch was aborted')
     rec, offs, _win = eng.fetch_examples(0, nGames)

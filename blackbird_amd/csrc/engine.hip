@@ -256,7 +256,7 @@ static int engine_alloc(bb_engine *e) {
         dalloc(e, d.eval_policy, n * PSTRIDE) || dalloc(e, d.ctr, n * 8) || dalloc(e, d.evals, n) || dalloc(e, d.out_action, n) ||
         dalloc(e, d.out_root_plays, n) || dalloc(e, d.out_child_plays, n * G::S) ||
         dalloc(e, d.out_root_winrate, n) || dalloc(e, d.out_child_value, n * G::S) || dalloc(e, e->d_u, n) ||
-        dalloc(e, e->d_actions, n) || dalloc(e, d.stamps, 16 * 64) || dalloc(e, d.resume_cur, n) ||
+        dalloc(e, e->d_actions, n) || dalloc(e, d.stamps, 16 * 64) || dalloc(e, d.visit_pool, 16) || dalloc(e, d.resume_cur, n) ||
         dalloc(e, d.resume_depth, n) || dalloc(e, d.post_count, 8) || dalloc(e, d.post_slot, n) ||
         false)
         return BB_ERR_HIP;
@@ -1108,6 +1108,8 @@ extern "C" int bb_selfplay_begin(bb_engine *e, int n_games, double temp) {
     });
 }
 
+__global__ void k_set_i32(int *p, int v) { *p = v; }
+
 template <class G>
 static int selfplay_rounds_async(bb_engine *e, int rounds) {
     if constexpr (G::GID == BB_GAME_DRAGONCHESS) {
@@ -1115,22 +1117,26 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
     } else {
         constexpr int PWMAX = NetPW<G>::v;
         if (e->mega && !e->general_net && e->net.R <= MEGA_RMAX && e->net.head_floats <= MEGA_HEAD_FLOATS) {
-            // persistent launches of at most 16 plies' worth of visits each: every spin loop inside is bounded by
-            // BB_QUEUE_LIMIT_S of wall clock, so one launch must stay far below it whatever the caller asks for
+            // persistent launches of at most 64 steps' worth of visits each (3 s at 4096 Connect4 games x 800 visits): every
+            // spin loop inside is bounded by BB_QUEUE_LIMIT_S of wall clock (30 s), so one launch must stay far below it
+            // whatever the caller asks for.  Not shorter than necessary either: a launch ends when its SLOWEST workgroup has
+            // given each of its games the requested visits, ~35 ms after the fastest one -- 4 % of a 16-step launch.
             TreeDev &d = e->dev;
             int nb = (d.n_slots + 15) / 16;
-            const int per_launch = 16 * (e->sims_now > 0 ? e->sims_now : 1);
+            int per_launch = (getenv("BB_LAUNCH_STEPS") ? atoi(getenv("BB_LAUNCH_STEPS")) : 64) * (e->sims_now > 0 ? e->sims_now : 1);
+            if (per_launch > (1 << 30) / d.n_slots) per_launch = (1 << 30) / d.n_slots; // the launch's visit pool is an int
             const int all_rounds = rounds;
           for (int done_rounds = 0; done_rounds < all_rounds; done_rounds += per_launch) {
             rounds = all_rounds - done_rounds < per_launch ? all_rounds - done_rounds : per_launch;
             bool timed = e->time_every > 0 && e->ev_used + 2 <= e->ev_pool.size();
             if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
             TreeDev dm = d;
+            k_set_i32<<<1, 1, 0, e->stream>>>(d.visit_pool, d.n_slots * rounds); // the launch's pool of visits (mega2.hip.h)
             const int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
             const int netw = getenv("BB_QUEUE_NETW") ? atoi(getenv("BB_QUEUE_NETW")) : 8; // network waves of the 12 (tuning)
-            if (netw == 7) k_selfplay_queue<G, 7><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
-            else if (netw == 6) k_selfplay_queue<G, 6><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
-            else k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, rounds, e->cfg.noise_on, lim);
+            if (netw == 7) k_selfplay_queue<G, 7><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, e->cfg.noise_on, lim);
+            else if (netw == 6) k_selfplay_queue<G, 6><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, e->cfg.noise_on, lim);
+            else k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, e->cfg.noise_on, lim);
             HIPCHK(hipGetLastError());
             if (timed) {
                 HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));

@@ -143,7 +143,7 @@ __device__ __attribute__((noinline)) void queue_push(QueueCtl *c, int *state_wor
 }
 
 template <class G, int NETW>
-__global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, NetDev nd, int visits, int noise_on, int limit_s) {
+__global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, NetDev nd, int noise_on, int limit_s) {
     constexpr int S = G::S, GW = 16, TREEW = 12 - NETW, GPT = (GW + TREEW - 1) / TREEW; // games per workgroup, tree waves, games per tree wave
     static_assert(GPT * S <= 64, "a tree wave holds at most 64 / S games");
     using NG = NetGeom<G, 1>;
@@ -155,6 +155,12 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
     __shared__ GameShadow<G, GW> shadow;
     __shared__ int gstate[GW];      // 0 owned by its tree wave, 1 leaf queued / being evaluated, 2 result published
     __shared__ int myslot[NETW];
+    // Visits are not dealt per game: the launch has ONE pool (dg.visit_pool = slots x visits) that the workgroups draw from
+    // in chunks, and every game of a workgroup keeps searching until the pool is dry.  With a fixed count per game the
+    // pipeline of a workgroup ran empty game by game at the end of every launch and the launch waited for its slowest
+    // workgroup (~35 ms of a 16-step launch); a game's results do not depend on when its visits happen.
+    __shared__ int wg_pool, wg_dry, wg_refill;
+    constexpr int CHUNK = GW * 32;
 #ifdef BB_STAMPS
     __shared__ long long ts_post[GW], ts_done[GW];
 #endif
@@ -168,6 +174,9 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
         qc.tail = 0;
         qc.tree_done = 0;
         qc.abort_flag = 0;
+        wg_pool = 0;
+        wg_dry = 0;
+        wg_refill = 0;
     }
     if (threadIdx.x < GW) gstate[threadIdx.x] = 0;
     if (threadIdx.x < MEGA2_QCAP) qc.q[threadIdx.x] = -1;
@@ -196,14 +205,26 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
         const int li = (l64 / S) * TREEW + tw, lane = l64 % S; // games are dealt round-robin to the tree waves
         const bool mine = l64 < GPT * S && li < GW && g0 + li < d.n_slots;
         const int g = li; // local game number: index of the LDS copies
-        int left = mine ? visits : 0;
+        bool alive = mine; // false once the slot has run out of games
 #ifdef BB_STAMPS
         long long t_work = 0, t_all0 = clock64(), n_calls = 0, n_lanes = 0, t_pick = 0, n_pick = 0;
 #endif
         for (;;) {
             int stt = mine ? lds_load(&gstate[li]) : 1;
-            bool ready = mine && left > 0 && stt != 1;
-            bool busy = mine && (left > 0 || stt == 1); // still owes visits, or a leaf of mine is in flight
+            const int pool = lds_load(&wg_pool), dry = lds_load(&wg_dry);
+            if (pool < CHUNK / 4 && !dry) { // (wave-uniform) top the workgroup's share up before it runs out
+                if (l64 == 0 && atomicCAS(&wg_refill, 0, 1) == 0) {
+                    int old = atomicSub(d.visit_pool, CHUNK);
+                    int got = old < 0 ? 0 : old < CHUNK ? old : CHUNK;
+                    if (got) atomicAdd(&wg_pool, got);
+                    else *(volatile int *)&wg_dry = 1;
+                    __threadfence_block();
+                    *(volatile int *)&wg_refill = 0;
+                }
+                if (pool <= 0) continue; // another wave's refill is on its way
+            }
+            bool ready = mine && alive && pool > 0 && stt != 1;
+            bool busy = mine && ((alive && pool > 0) || (alive && !dry) || stt == 1); // visits left to draw, or a leaf of mine is in flight
             if (!__any(busy)) break;
             if (__any(ready)) {
                 __threadfence_block(); // acquire: the network wave's results for state 2
@@ -219,8 +240,11 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
 #endif
                 if (ready) {
                     posted = async_game<G>(d, g, lane);
-                    left--;
-                    if (d.game_lid[g] < 0) left = 0; // slot ran out of games
+                    if (d.game_lid[g] < 0) alive = false; // slot ran out of games
+                }
+                {
+                    int used = __popcll(__ballot(ready && lane == 0));
+                    if (l64 == 0) atomicSub(&wg_pool, used);
                 }
 #ifdef BB_STAMPS
                 if (ready && lane == 0 && posted) ts_post[li] = wall_clock64();

@@ -113,6 +113,8 @@ struct TreeDev {
     // indexes them with the LOCAL slot number; the node pool stays in HBM and is indexed with pool_g0 + local number.
     // Everywhere else pool_g0 is 0 and the slot number is the engine's.
     int pool_g0;
+    // visits (async_game calls) the running persistent launch may still hand out; its workgroups draw them in chunks
+    int *visit_pool;
     float noise_alpha;
     unsigned long long *stamps; // diagnostic build only (BB_STAMPS): [apply, fence, select, levels, waves]
 };
