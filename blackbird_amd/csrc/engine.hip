@@ -1193,13 +1193,17 @@ extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
         if (e->async_selfplay) return selfplay_rounds_async<G>(e, plies * e->sims_now);
         if constexpr (G::GID == BB_GAME_DRAGONCHESS) {
             if (e->dc_fused && e->has_weights && !e->general_net && e->net.head_floats <= DC_HEAD_FLOATS) {
-                // at most 16 plies per launch (a launch is plies x sims x ~70 us long; nothing inside can spin)
-                for (int done = 0; done < plies; done += 16) {
-                    const int now = plies - done < 16 ? plies - done : 16;
+                // at most 64 plies' worth of simulations per launch (a launch is plies x sims x ~45 us long; nothing inside can
+                // spin); the waves draw them from one pool (mega_dc.hip.h)
+                int cap = 64;
+                if ((long)cap * e->sims_now * e->dev.n_slots > (1l << 30)) cap = (int)((1l << 30) / ((long)e->sims_now * e->dev.n_slots));
+                if (cap < 1) cap = 1;
+                for (int done = 0; done < plies; done += cap) {
+                    const int now = plies - done < cap ? plies - done : cap;
                     bool timed = e->time_every > 0 && e->ev_used + 2 <= e->ev_pool.size();
                     if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
-                    k_dc_selfplay_fused<<<nblk((size_t)e->dev.n_slots * 64), 256, 0, e->stream>>>(e->dev, e->edges, e->net, now, e->sims_now,
-                                                                                                  e->cfg.noise_on);
+                    k_set_i32<<<1, 1, 0, e->stream>>>(e->dev.visit_pool, e->dev.n_slots * now * e->sims_now);
+                    k_dc_selfplay_fused<<<nblk((size_t)e->dev.n_slots * 64), 256, 0, e->stream>>>(e->dev, e->edges, e->net, e->cfg.noise_on);
                     HIPCHK(hipGetLastError());
                     if (timed) {
                         HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));

@@ -40,6 +40,16 @@ __device__ __attribute__((noinline)) void dc_fused_net(const NetDev &nd_, const 
                              nullptr, nullptr, nullptr, DragonChess::A, true, &hl->h);
     __threadfence_block();
 }
+// The evaluated leaf alone (what dc_fused_tree does first): the last thing a wave does when the launch's pool of
+// simulations is dry, so that nothing of the evaluation has to outlive the launch (its policy summary `hl` is in LDS).
+__device__ __attribute__((noinline)) void dc_fused_apply(const TreeDev &d_, const DCEdges &E_, int g, int lane, float *tl, const DCHeadLocal *hl) {
+    const TreeDev &d = *as_lds(&d_);
+    const DCEdges &E = *as_lds(&E_);
+    tl = as_lds(tl);
+    hl = as_lds(hl);
+    dc_phase_apply(d, E, g, lane, tl, hl);
+    __threadfence_block();
+}
 __device__ __attribute__((noinline)) void dc_fused_move(const TreeDev &d_, const DCEdges &E_, int g, int lane, float *tl, const DCHeadLocal *hl) {
     const TreeDev &d = *as_lds(&d_);
     const DCEdges &E = *as_lds(&E_);
@@ -92,7 +102,9 @@ struct DCShadow {
     }
 };
 
-__global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdges E_arg, NetDev nd_arg, int plies, int sims, int noise_on) {
+#define DC_SIM_CHUNK 20 // simulations a wave draws from the launch's pool at a time (~1 ms of work)
+
+__global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdges E_arg, NetDev nd_arg, int noise_on) {
     using NG = NetGeom<DragonChess, 1>;
     // the tree's scratch (the 4032-float policy image) and the network's activations are never live together
     constexpr int TREE_BYTES = DC_LDS_FLOATS * 4, NET_BYTES = NG::WAVE_FLOATS * 4;
@@ -145,25 +157,43 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
     if (lane < 16) ((unsigned long long *)(lds + DC_STAMP_OFF))[lane] = 0;
 #endif
     __threadfence_block();
-    for (int p = 0; mine && p < plies; p++) {
+    // The launch has one pool of simulations (d.visit_pool = slots x plies x simulations per move) that the waves draw from
+    // in small chunks until it is dry: every wave then stops within a chunk of the others, wherever its game is in its move
+    // (sims_left carries over), instead of the launch waiting for the game with the slowest `plies` moves.
+    int chunk = 0;
+    while (mine) {
         if (d.game_lid[g] < 0) break; // this slot has played its last game
-        for (int s = 0; s < sims; s++) {
-#ifdef BB_STAMPS
-            long long c0 = clock64();
-#endif
-            dc_fused_tree(d, E, g, lane, tl, hl);
-#ifdef BB_STAMPS
-            long long c1 = clock64();
-#endif
-            if (d.pend_leaf[g] >= 0) // (uniform) a leaf was posted: evaluate it right here
-                dc_fused_net(nd, d, &myslot[wv], nl, hl);
-#ifdef BB_STAMPS
-            DST(0, c1 - c0);          // tree phases (tools/dc_stamps.py)
-            DST(2, clock64() - c1);   // network
-            DST(4, 1);
-#endif
+        if (d.sims_left[g] <= 0) {    // MCTS.FindMove's tail and the self-play loop body (applies the last leaf first)
+            dc_fused_move(d, E, g, lane, tl, hl);
+            continue;
         }
-        dc_fused_move(d, E, g, lane, tl, hl);
+        if (chunk == 0) {
+            int got = 0;
+            if (lane == 0) {
+                int old = atomicSub(d.visit_pool, DC_SIM_CHUNK);
+                got = old < 0 ? 0 : old < DC_SIM_CHUNK ? old : DC_SIM_CHUNK;
+            }
+            chunk = __builtin_amdgcn_readfirstlane(got);
+            if (chunk == 0) {
+                if (d.pend_leaf[g] >= 0) dc_fused_apply(d, E, g, lane, tl, hl);
+                break;
+            }
+        }
+        chunk--;
+#ifdef BB_STAMPS
+        long long c0 = clock64();
+#endif
+        dc_fused_tree(d, E, g, lane, tl, hl);
+#ifdef BB_STAMPS
+        long long c1 = clock64();
+#endif
+        if (d.pend_leaf[g] >= 0) // (uniform) a leaf was posted: evaluate it right here
+            dc_fused_net(nd, d, &myslot[wv], nl, hl);
+#ifdef BB_STAMPS
+        DST(0, c1 - c0);          // tree phases (tools/dc_stamps.py)
+        DST(2, clock64() - c1);   // network
+        DST(4, 1);
+#endif
     }
 #ifdef BB_STAMPS
     if (mine && lane == 0 && d.stamps)
