@@ -5,6 +5,7 @@
 #include "../../include/blackbird_hip.h"
 #include "eval.hip.h"
 #include "net.hip.h"
+#include "net_x3.hip.h"
 #include "gnet.hip.h"
 #include "tree.hip.h"
 #include "tree_dc.hip.h"
@@ -186,6 +187,8 @@ struct bb_engine {
     DCEdges edges; // DragonChess only
     int32_t *d_child_action = nullptr;
     NetDev net;
+    NetX3 x3 = {nullptr, nullptr}; // 16-filter network of a dense game on the bf16 matrix pipe (net_x3.hip.h); null: float32 MFMA path
+    size_t x3_bytes = 0;
     bool has_weights = false;
     int net_F = 0, net_C = 0;
     bool general_net = false; // F != 16 (or BB_GNET=1): one implicit-GEMM launch per conv layer (gnet.hip.h)
@@ -640,6 +643,66 @@ static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slo
     return BB_OK;
 }
 
+// ---- operands of net_x3.hip.h: every weight as three bf16 planes (w = w1 + w2 + w3 exactly), in A-operand lane order ----
+static uint16_t bf16_rne(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf16_value(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static void bf16_split3(float v, uint16_t out[3]) {
+    out[0] = bf16_rne(v);
+    float r = v - bf16_value(out[0]);
+    out[1] = bf16_rne(r);
+    r = r - bf16_value(out[1]);
+    out[2] = bf16_rne(r);
+}
+// w0: [plane][lane][8] (taps 2g, 2g + 1 x 4 input planes) then [plane][lane][4] (tap 8, lane group 0 only)
+// wt: per layer [slice 0..3][plane][lane][8] (slices = taps (0,1), (3,4), (6,7), (2,5); lane group g: tap g >> 1 of the
+//     slice, channels 8 (g & 1) .. + 7) then [plane][lane][4] (tap 8, channels 4g .. 4g + 3)
+static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vector<uint16_t> &wt) {
+    const int F = 16, C = w->C, R = w->R;
+    w0.assign((3 * 64 * 8 + 3 * 64 * 4), 0);
+    wt.assign((size_t)2 * R * (4 * 3 * 64 * 8 + 3 * 64 * 4), 0);
+    uint16_t h[3];
+    for (int lane = 0; lane < 64; lane++) {
+        const int f = lane & 15, g = lane >> 4;
+        for (int i = 0; i < 8; i++) {
+            int tap = 2 * g + (i >> 2), ch = i & 3;
+            bf16_split3(ch < C ? w->conv0_k[((size_t)tap * C + ch) * F + f] : 0.f, h);
+            for (int q = 0; q < 3; q++) w0[((size_t)q * 64 + lane) * 8 + i] = h[q];
+        }
+        for (int i = 0; i < 4; i++) {
+            bf16_split3((g == 0 && i < C) ? w->conv0_k[((size_t)8 * C + i) * F + f] : 0.f, h);
+            for (int q = 0; q < 3; q++) w0[(size_t)3 * 64 * 8 + ((size_t)q * 64 + lane) * 4 + i] = h[q];
+        }
+    }
+    static const int slice_taps[4][2] = {{0, 1}, {3, 4}, {6, 7}, {2, 5}};
+    const size_t per_layer = 4 * 3 * 64 * 8 + 3 * 64 * 4;
+    for (int l = 0; l < 2 * R; l++) {
+        uint16_t *o = wt.data() + (size_t)l * per_layer;
+        for (int lane = 0; lane < 64; lane++) {
+            const int f = lane & 15, g = lane >> 4;
+            for (int sl = 0; sl < 4; sl++)
+                for (int i = 0; i < 8; i++) {
+                    int tap = slice_taps[sl][g >> 1], ch = 8 * (g & 1) + i;
+                    bf16_split3(w->blk_k[(((size_t)l * 9 + tap) * F + ch) * F + f], h);
+                    for (int q = 0; q < 3; q++) o[(((size_t)sl * 3 + q) * 64 + lane) * 8 + i] = h[q];
+                }
+            for (int i = 0; i < 4; i++) {
+                bf16_split3(w->blk_k[(((size_t)l * 9 + 8) * F + (4 * g + i)) * F + f], h);
+                for (int q = 0; q < 3; q++) o[(size_t)4 * 3 * 64 * 8 + ((size_t)q * 64 + lane) * 4 + i] = h[q];
+            }
+        }
+    }
+}
+
 extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     if (!e || !w) return fail(BB_ERR_ARG, "null argument");
     const bb_game_info &gi = e->info;
@@ -716,6 +779,26 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     if (!wt.empty()) HIPCHK(hipMemcpy(d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_epi, epi.data(), epi.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_head, head.data(), head.size() * 4, hipMemcpyHostToDevice));
+    // the bf16-pipe form of the same network (dense games, 16 filters); BB_NET_X3=0 keeps the float32 MFMA path
+    {
+        const bool want = F == 16 && C <= 4 && !e->general_net && !(getenv("BB_NET_X3") && atoi(getenv("BB_NET_X3")) == 0);
+        if (want) {
+            std::vector<uint16_t> xw0, xwt;
+            pack_x3(w, xw0, xwt);
+            const size_t bytes = (xw0.size() + xwt.size()) * 2;
+            unsigned char *d_x = (unsigned char *)e->x3.w0;
+            if (!d_x || bytes != e->x3_bytes) {
+                if (dalloc(e, d_x, bytes + 16, false)) return BB_ERR_HIP;
+                e->x3_bytes = bytes;
+            }
+            HIPCHK(hipMemcpy(d_x, xw0.data(), xw0.size() * 2, hipMemcpyHostToDevice));
+            if (!xwt.empty()) HIPCHK(hipMemcpy(d_x + xw0.size() * 2, xwt.data(), xwt.size() * 2, hipMemcpyHostToDevice));
+            e->x3.w0 = d_x;
+            e->x3.wt = d_x + xw0.size() * 2;
+        } else {
+            e->x3.w0 = e->x3.wt = nullptr;
+        }
+    }
     nd.R = R;
     nd.D = D;
     nd.A = A;
@@ -750,6 +833,14 @@ static int launch_net(bb_engine *e, int n, const typename G::State *states, cons
     // positions per wave: the fewest that still put a wave on every SIMD (1024 waves) -- a single FindMove position
     // must not pay for the 11 MFMA tiles of a 4-position wave
     constexpr int PW = NetPW<G>::v;
+    if constexpr (G::C <= 4) {
+        if (e->x3.w0) { // one position per wave on the bf16 pipe: the same arithmetic everywhere (bb_net_eval, search, self-play)
+            k_net_x3<G><<<(n + 3) / 4, 256, 0, st>>>(e->net, e->x3, n, nullptr, nullptr, states, planes, game_id, serial, noise, value,
+                                                     logits, policy, pstride);
+            HIPCHK(hipGetLastError());
+            return BB_OK;
+        }
+    }
     if (PW > 1 && n <= 1024) {
         k_net_fused16<G, 1><<<(n + 3) / 4, 256, 0, st>>>(e->net, n, states, planes, game_id, serial, noise, value, logits, policy,
                                                          pstride);
@@ -1134,9 +1225,16 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
             k_set_i32<<<1, 1, 0, e->stream>>>(d.visit_pool, d.n_slots * rounds); // the launch's pool of visits (mega2.hip.h)
             const int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
             const int netw = getenv("BB_QUEUE_NETW") ? atoi(getenv("BB_QUEUE_NETW")) : 8; // network waves of the 12 (tuning)
-            if (netw == 7) k_selfplay_queue<G, 7><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, e->cfg.noise_on, lim);
-            else if (netw == 6) k_selfplay_queue<G, 6><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, e->cfg.noise_on, lim);
-            else k_selfplay_queue<G, 8><<<nb, MEGA2_THREADS, 0, e->stream>>>(dm, e->net, e->cfg.noise_on, lim);
+            if (e->x3.w0) { // bf16-pipe network: 8 waves of 256 VGPRs -- Connect4 5 network + 3 tree waves, TicTacToe 4 + 4
+                if constexpr (G::S <= 8) {
+                    if (getenv("BB_QUEUE_NETW") && netw == 4) k_selfplay_queue<G, 4, true, 8><<<nb, 512, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim);
+                    else k_selfplay_queue<G, 5, true, 8><<<nb, 512, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim);
+                } else {
+                    k_selfplay_queue<G, 4, true, 8><<<nb, 512, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim);
+                }
+            } else if (netw == 7) k_selfplay_queue<G, 7><<<nb, 768, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim);
+            else if (netw == 6) k_selfplay_queue<G, 6><<<nb, 768, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim);
+            else k_selfplay_queue<G, 8><<<nb, 768, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim);
             HIPCHK(hipGetLastError());
             if (timed) {
                 HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));
@@ -1165,6 +1263,11 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
                                                 d.leaf_serial, e->cfg.noise_on, d.eval_value, nullptr, d.eval_policy, G::S, st,
                                                 d.slot_offset);
                         if (rc) return rc;
+                    } else if (e->x3.w0) {
+                        if constexpr (G::C <= 4)
+                            k_net_x3<G><<<(d.n_slots + 3) / 4, 256, 0, st>>>(e->net, e->x3, 0, d.post_count + (round & 3), d.post_slot, ls,
+                                                                              nullptr, d.leaf_game_id, d.leaf_serial, e->cfg.noise_on,
+                                                                              d.eval_value, nullptr, d.eval_policy, G::S);
                     } else
                     k_net_compact<G, PWMAX><<<nb, 256, 0, st>>>(e->net, d.post_count + (round & 3), d.post_slot, ls,
                                                                  d.leaf_game_id, d.leaf_serial, e->cfg.noise_on, d.eval_value,

@@ -15,12 +15,14 @@
 // launch with the abort word set (reported through the overflow counter) instead of hanging the GPU.
 #pragma once
 #include "net.hip.h"
+#include "net_x3.hip.h"
 #include "tree.hip.h"
 
 #define MEGA_RMAX 4          // residual blocks whose weights fit the 160 KiB LDS next to the activations
 #define MEGA_HEAD_FLOATS 256 // packed head parameters that fit next to them
 
-#define MEGA2_THREADS 768 // 12 waves: NETW network waves + (12 - NETW) tree waves
+// Waves of the workgroup = NETW network waves + the tree waves.  float32-MFMA network: 12 waves (8 + 4) at 168 VGPRs;
+// bf16-pipe network (X3): 8 waves at 256 VGPRs -- 5 + 3 for Connect4, 4 + 4 for TicTacToe (4 games of 16 lanes per tree wave).
 #define MEGA2_QCAP 32
 #ifndef BB_TREE_IDLE_SLEEP
 #define BB_TREE_IDLE_SLEEP 4 // s_sleep argument (x 64 cycles) of a tree wave that finds none of its games ready
@@ -29,7 +31,7 @@
 #define BB_NET_IDLE_SLEEP 4  // ... of a network wave that finds the queue empty
 #endif
 #ifndef BB_NET_APPLIES
-#define BB_NET_APPLIES 1 // the network wave that evaluated a leaf also expands it and backs its value up (phase_apply), see below
+#define BB_NET_APPLIES -1 // tuning override of NET_APPLIES (k_selfplay_queue): 1 network waves apply their result, 0 tree waves do
 #endif
 #ifndef BB_QUEUE_WMODE
 #define BB_QUEUE_WMODE 2 // net.hip.h conv_layer: weights in LDS, next tap's operands requested ahead of this tap's MFMAs
@@ -142,14 +144,25 @@ __device__ __attribute__((noinline)) void queue_push(QueueCtl *c, int *state_wor
     }
 }
 
-template <class G, int NETW>
-__global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, NetDev nd, int noise_on, int limit_s) {
-    constexpr int S = G::S, GW = 16, TREEW = 12 - NETW, GPT = (GW + TREEW - 1) / TREEW; // games per workgroup, tree waves, games per tree wave
+// X3: the network runs on the bf16 matrix pipe (net_x3.hip.h); its packed operands are 1.5x the float32 ones, so fewer
+// network waves fit next to them (5 at 4 residual blocks) -- they need far fewer matrix cycles per evaluation.
+template <class G, int NETW, bool X3 = false, int WAVES = 12>
+__global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDev nd, NetX3 x3, int noise_on, int limit_s) {
+    constexpr int MEGA2_THREADS = WAVES * 64;
+    // The wave that holds an evaluation also expands the leaf and backs the value up when the tree waves are the busier side
+    // (float32 network: they share their SIMD's vector ALUs with the f32 MFMAs); beside the bf16-pipe network the network
+    // waves are the busy side and the tree waves take the result back.
+    constexpr bool NET_APPLIES = BB_NET_APPLIES >= 0 ? BB_NET_APPLIES != 0 : !X3;
+    constexpr int S = G::S, GW = 16, TREEW = WAVES - NETW, GPT = (GW + TREEW - 1) / TREEW; // games per workgroup, tree waves, games per tree wave
     static_assert(GPT * S <= 64, "a tree wave holds at most 64 / S games");
     using NG = NetGeom<G, 1>;
     constexpr int RMAX = MEGA_RMAX, STEPS0 = NG::STEPS0;
-    constexpr int WT_F = 2 * RMAX * 9 * 64 * 4, W0_F = STEPS0 * 64, EPI_F = (1 + 2 * RMAX) * 48, HEAD_F = MEGA_HEAD_FLOATS;
-    __shared__ __attribute__((aligned(16))) float lds[NETW * NG::WAVE_FLOATS];
+    using XG = X3Geom<G>;
+    constexpr int EPI_F = (1 + 2 * RMAX) * 48, HEAD_F = MEGA_HEAD_FLOATS;
+    // operand floats: float32 form [wt][w0], x3 form [w0 bytes][wt bytes]; then epilogue constants and head parameters
+    constexpr int WT_F = X3 ? 2 * RMAX * XG::LAYER_B / 4 : 2 * RMAX * 9 * 64 * 4, W0_F = X3 ? XG::W0_B / 4 : STEPS0 * 64;
+    constexpr int WAVE_F = X3 ? XG::WAVE_BYTES / 4 : NG::WAVE_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[NETW * WAVE_F];
     __shared__ __attribute__((aligned(16))) float wlds[WT_F + W0_F + EPI_F + HEAD_F];
     __shared__ QueueCtl qc;
     __shared__ GameShadow<G, GW> shadow;
@@ -180,12 +193,17 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
     }
     if (threadIdx.x < GW) gstate[threadIdx.x] = 0;
     if (threadIdx.x < MEGA2_QCAP) qc.q[threadIdx.x] = -1;
-    for (int i = threadIdx.x; i < NETW * NG::WAVE_FLOATS; i += MEGA2_THREADS) lds[i] = 0.f;
+    for (int i = threadIdx.x; i < NETW * WAVE_F; i += MEGA2_THREADS) lds[i] = 0.f;
     NetDev ndl = nd;
+    NetX3 x3l = x3;
     {
-        const float *gwt = (const float *)nd.wt;
-        for (int i = threadIdx.x; i < 2 * nd.R * 9 * 64 * 4; i += MEGA2_THREADS) wlds[i] = gwt[i];
-        for (int i = threadIdx.x; i < W0_F; i += MEGA2_THREADS) wlds[WT_F + i] = nd.w0[i];
+        const float *gwt = X3 ? (const float *)x3.wt : (const float *)nd.wt;
+        const float *gw0 = X3 ? (const float *)x3.w0 : nd.w0;
+        const int wt_used = X3 ? 2 * nd.R * XG::LAYER_B / 4 : 2 * nd.R * 9 * 64 * 4;
+        for (int i = threadIdx.x; i < wt_used; i += MEGA2_THREADS) wlds[i] = gwt[i];
+        for (int i = threadIdx.x; i < W0_F; i += MEGA2_THREADS) wlds[WT_F + i] = gw0[i];
+        x3l.wt = (const unsigned char *)wlds;
+        x3l.w0 = (const unsigned char *)(wlds + WT_F);
         for (int i = threadIdx.x; i < (1 + 2 * nd.R) * 48; i += MEGA2_THREADS) wlds[WT_F + W0_F + i] = nd.epi[i];
         for (int i = threadIdx.x; i < nd.head_floats; i += MEGA2_THREADS) wlds[WT_F + W0_F + EPI_F + i] = nd.head[i];
         ndl.wt = (const f32x4 *)wlds;
@@ -238,10 +256,29 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
                     n_pick++;
                 }
 #endif
+#ifdef BB_STAMPS_LIGHT
+                int ll = 0, lv = 0, lld = 0, lpu = 0;
+                if (ready) {
+                    posted = async_game<G>(d, g, lane, ll, lv, lld, lpu);
+                    if (d.game_lid[g] < 0) alive = false;
+                }
+                { // the game with the most levels ran the whole length of the call: its loop time per level is undiluted
+                    int m = lv;
+                    for (int o = 32; o; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+                    unsigned long long who = __ballot(ready && lane == 0 && lv == m);
+                    if (who && l64 == (int)__builtin_ctzll(who) && d.stamps) {
+                        atomicAdd(&d.stamps[6], (unsigned long long)ll);
+                        atomicAdd(&d.stamps[7], (unsigned long long)lv);
+                        atomicAdd(&d.stamps[11], (unsigned long long)lld);   // (LIGHT: 11 / 12 carry the split, not the call totals)
+                        atomicAdd(&d.stamps[12], (unsigned long long)lpu);
+                    }
+                }
+#else
                 if (ready) {
                     posted = async_game<G>(d, g, lane);
                     if (d.game_lid[g] < 0) alive = false; // slot ran out of games
                 }
+#endif
                 {
                     int used = __popcll(__ballot(ready && lane == 0));
                     if (l64 == 0) atomicSub(&wg_pool, used);
@@ -277,7 +314,7 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
         }
 #endif
     } else { // ---------------- network waves ----------------
-        float *wl = lds + wave * NG::WAVE_FLOATS;
+        float *wl = lds + wave * WAVE_F;
 #ifdef BB_STAMPS
         long long t_work = 0, t_all0 = clock64(), n_evals = 0, t_qwait = 0;
 #endif
@@ -304,20 +341,30 @@ __global__ void __launch_bounds__(MEGA2_THREADS) k_selfplay_queue(TreeDev dg, Ne
                 if (l64 < G::A) d.eval_policy[(size_t)slot * S + l64] = bb_hash_policy(z, l64);
             }
 #else
-            net_body<G, 1, BB_QUEUE_WMODE>(ndl, 1, 0, &myslot[wave], wl, (const typename G::State *)d.leaf_state, nullptr, d.leaf_game_id,
-                           d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false);
+            if constexpr (X3)
+                net_body_x3<G, true>(ndl, x3l, 1, 0, &myslot[wave], (unsigned char *)wl, (const typename G::State *)d.leaf_state, nullptr,
+                                     d.leaf_game_id, d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false);
+            else
+                net_body<G, 1, BB_QUEUE_WMODE>(ndl, 1, 0, &myslot[wave], wl, (const typename G::State *)d.leaf_state, nullptr,
+                                               d.leaf_game_id, d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false);
 #endif
-#if BB_NET_APPLIES
+            if constexpr (NET_APPLIES) {
             // The evaluated leaf is expanded and its value backed up right here, by the wave that holds the result, instead
             // of waiting until the game's tree wave comes round (the tree waves are every game's latency chain and the
             // busier side of the queue: 91 % against 67 %; a result used to wait ~10 us to be picked up).  Same function,
             // same lane layout (lane i <-> child slot i on lanes 0..S-1), so the same bits.
             __threadfence_block(); // the mailbox writes of net_body (other lanes) before phase_apply reads them
+#ifdef BB_STAMPS_NET
+            long long _na = clock64();
+#endif
             if (l64 < S) {
                 phase_apply<G>(d, li, l64);
                 if (l64 == 0) d.sims_left[li] -= 1;
             }
+#ifdef BB_STAMPS_NET
+            if (l64 == 0) atomicAdd(&g_net_stamps[5], (unsigned long long)(clock64() - _na));
 #endif
+            }
             release_global_then_lds(); // value / policy (and the tree rows) before the state word
 #ifdef BB_STAMPS
             if (l64 == 0) ts_done[li] = wall_clock64();

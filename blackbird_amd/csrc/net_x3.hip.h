@@ -1,0 +1,376 @@
+// net_x3.hip.h -- the 16-filter residual tower on the bf16 matrix pipe, float32 results by a three-way operand split.
+//
+// Why: on gfx950 the f32 MFMA (v_mfma_f32_16x16x4_f32, 64 FLOP/cycle/SIMD) runs on the SIMD's vector ALUs -- while one
+// wave issues it back to back, every other wave's vector instruction on that SIMD waits ~70 cycles (tools/micro/coissue:
+// x10 for a dependent v_fma chain, x7.5 for a ds_read chain; wave priority changes nothing).  The tree waves and the
+// heads / epilogues of the persistent self-play kernel therefore PAY for every f32 MFMA cycle: matrix and vector time add
+// up, and the kernel sat at ~87 % of the SIMDs' combined issue time.  v_mfma_f32_16x16x32_bf16 has its own pipe (16
+// cycles for 8x the K, vector issue held for 8 of them; the same probes slow down x1.1 - x1.4 beside it).
+//
+// How: a float32 value is the exact sum of three bf16 values (8 + 8 + 8 significant bits):
+//     x = x1 + x2 + x3,   x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
+// and  w * x = sum_{i + j <= 4} w_i x_j  up to terms below 2^-24 |w x|  (w2 x3, w3 x2, w3 x3), each product exact in the
+// f32 accumulator.  Six bf16 MFMAs (w1x1, w1x2, w2x1, w1x3, w2x2, w3x1) at 16 cycles for K = 32 replace eight f32 MFMAs
+// at 32 cycles for K = 4 each: 96 against 256 cycles per 32-deep slice of a 16 x 16 tile.  The accumulation order inside
+// the MFMA differs from the oracle's k-ordered fmaf chain, so logits agree with the oracle to ~1e-6 instead of bit for
+// bit (north star: 1e-5; tests/test_gpu_net.py states the bound).  The tree arithmetic is unaffected: the oracle's
+// search is compared on the evaluations the engine itself produced (bb_net_eval_keyed, tests/test_gpu_noise_parity.py).
+//
+// Layout (one wave = one position, its activations never leave LDS):
+//   X    [slot][plane 0..2][16 ch] bf16 = 96 B per pixel slot (zero halo as in net.hip.h); the three planes of a pixel's 8
+//        channels are one ds_read_b128 each; written in place (a layer's reads are complete before its epilogue starts,
+//        the block input for the skip connection stays in registers)
+//   inp  [slot][4 ch] bf16: the input planes (small integers: exact in bf16, no split)
+//   the last layer leaves float32 [slot][16 ch] in the first 64 B of each interior slot for the heads.
+//   K order of a tower layer: taps (0,1), (3,4), (6,7), (2,5) as four K = 32 slices (lane group g = lane >> 4 holds
+//   channels 8 (g & 1) .. +7 of the slice's tap g >> 1), then tap 8 as one K = 16 slice (v_mfma_f32_16x16x16_bf16).
+//   Weights: pre-split and pre-swizzled on the host into the A-operand lane order (engine.hip: pack_x3).
+#pragma once
+#include "net.hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <class G>
+struct X3Geom {
+    static constexpr int H = G::H, W = G::W, CIN = G::C, A = G::A, HW = H * W;
+    static_assert(CIN <= 4, "the first conv packs 4 input planes per tap");
+    static_assert(HW <= 64, "one lane per pixel in the heads");
+    static constexpr int SLOTS = (H + 2) * (W + 1) + 1;
+    static constexpr int NT = (HW + 15) / 16;
+    static constexpr int SLOT_B = 96;                              // bytes of X per slot
+    static constexpr int X_B = SLOTS * SLOT_B;
+    static constexpr int INP_B = (SLOTS * 8 + 15) / 16 * 16;
+    static constexpr int STATE_B = ((int)sizeof(typename G::State) + 15) / 16 * 16;
+    static constexpr int WAVE_BYTES = X_B + INP_B + STATE_B;
+    // packed weights (bytes): a tower layer = 4 slices x 3 planes x 64 lanes x 16 B + tap 8: 3 planes x 64 lanes x 8 B
+    static constexpr int LAYER_B = 4 * 3 * 64 * 16 + 3 * 64 * 8;   // 13 824
+    static constexpr int W0_B = 3 * 64 * 16 + 3 * 64 * 8;          // first conv: taps 0..7 (K = 32) + tap 8 (K = 16)
+};
+
+struct NetX3 {           // device pointers of the packed operands (nullptr: this network has no x3 form)
+    const unsigned char *w0; // X3Geom::W0_B
+    const unsigned char *wt; // [2R] x LAYER_B
+};
+
+__device__ __forceinline__ unsigned bf16_bits(float v) { // round to nearest even, as v_cvt_pk_bf16_f32 does for finite values
+    __bf16 h = (__bf16)v;
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
+
+// Between a K = 32 and a K = 16 MFMA that accumulate into the same registers.  Measured on gfx950 / ROCm 7.2: with the two
+// opcodes back to back (v_mfma_f32_16x16x32_bf16 -> v_mfma_f32_16x16x16_bf16 on the same accumulator, nothing in between)
+// the second one read its SrcC before the first had written it and that MFMA's contribution was lost -- the compiler
+// inserts no wait states there.  So the two kinds are never interleaved, and every switch waits explicitly.
+__device__ __forceinline__ void x3_mfma_switch() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15");
+    asm volatile("s_nop 15");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// y[0..3] -> three bf16 planes, each packed as 2 dwords (4 x bf16)
+__device__ __forceinline__ void x3_split4(const f32x4 y, u32x2 &p1, u32x2 &p2, u32x2 &p3) {
+    float r1[4], r2[4];
+    unsigned a[4], b[4], c[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        a[r] = bf16_bits(y[r]);
+        r1[r] = y[r] - __uint_as_float(a[r] << 16);
+        b[r] = bf16_bits(r1[r]);
+        r2[r] = r1[r] - __uint_as_float(b[r] << 16);
+        c[r] = bf16_bits(r2[r]);
+    }
+    p1 = u32x2{a[0] | (a[1] << 16), a[2] | (a[3] << 16)};
+    p2 = u32x2{b[0] | (b[1] << 16), b[2] | (b[3] << 16)};
+    p3 = u32x2{c[0] | (c[1] << 16), c[2] | (c[3] << 16)};
+}
+
+// WLDS: the packed weights (x3.w0 / x3.wt, nd.epi, nd.head) are in LDS (persistent kernel) -- else global (L2-resident).
+template <class G, bool WLDS>
+__device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, int n, int pos0, const int *slot_list,
+                                            unsigned char *wl, const typename G::State *states, const int8_t *planes,
+                                            const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
+                                            float *logits_out, float *policy_out, int pstride, bool zero_lds) {
+    using XG = X3Geom<G>;
+    constexpr int W = XG::W, CIN = XG::CIN, HW = XG::HW, NT = XG::NT, SB = XG::SLOT_B;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, nn = lane & 15, gh = g >> 1, gl = g & 1;
+    unsigned char *X = wl;
+    unsigned char *inp = wl + XG::X_B;
+    typename G::State *sst = (typename G::State *)(wl + XG::X_B + XG::INP_B);
+    auto OI = [&](int pos) { return slot_list ? slot_list[pos] : pos; };
+    const bool live = pos0 < n;
+#ifdef BB_STAMPS_NET
+    long long _ns = clock64();
+#endif
+    if (nd.dbg & 32) { // debug: prove the kernel runs and writes
+        if (lane == 0 && value_out) value_out[OI(pos0)] = 123.0f + pos0;
+        return;
+    }
+
+    // ---- prologue: the board, the first conv's operands, zero fill -------------------------------------------------
+    const typename G::State my_state = planes ? G::initial() : states[OI(live ? pos0 : 0)];
+    const unsigned char *w0p = x3.w0;
+    bf16x8 w0a[3];
+    s16x4 w0b[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        w0a[q] = *(const bf16x8 *)(w0p + (q * 64 + lane) * 16);
+        w0b[q] = *(const s16x4 *)(w0p + 3 * 64 * 16 + (q * 64 + lane) * 8);
+    }
+    const f32x4 bias0 = *(const f32x4 *)(nd.epi + 4 * g), scale0 = *(const f32x4 *)(nd.epi + 16 + 4 * g),
+                shift0 = *(const f32x4 *)(nd.epi + 32 + 4 * g);
+    if (zero_lds) {
+        u32x4 z = {0u, 0u, 0u, 0u};
+        for (int i = lane; i < XG::WAVE_BYTES / 16; i += 64) ((u32x4 *)wl)[i] = z;
+    }
+    wave_lds_handover();
+    if (!planes && lane == 0) *sst = my_state;
+    wave_lds_handover();
+    if (lane < HW && live) { // input planes of pixel `lane`: 4 x bf16 (the int8 plane values are exact in bf16)
+        const int y = lane / W, x = lane % W;
+        int8_t v[4] = {0, 0, 0, 0};
+        if (planes) {
+            const int8_t *src = planes + ((size_t)pos0 * HW + lane) * CIN;
+#pragma unroll
+            for (int c = 0; c < CIN; c++) v[c] = src[c];
+        } else {
+            int8_t e[CIN];
+            G::encode_cell(*sst, y, x, e);
+#pragma unroll
+            for (int c = 0; c < CIN; c++) v[c] = e[c];
+        }
+        unsigned b[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) b[c] = __float_as_uint((float)v[c]) >> 16;
+        *(u32x2 *)(inp + ((y + 1) * (W + 1) + (x + 1)) * 8) = u32x2{b[0] | (b[1] << 16), b[2] | (b[3] << 16)};
+    }
+    // ---- per-tile addressing (bytes).  Offsets are biased by the window's top-left tap (TAP0 slots), so every tap is a
+    // non-negative immediate; MFMA columns past the last pixel repeat the last pixel (same values to the same addresses).
+    constexpr int TAP0 = (W + 1) + 1;
+    int aA[NT], aB[NT], aC[NT], aO[NT], iA[NT];
+    auto tapoff = [](int tap) { return (tap / 3) * (W + 1) + (tap % 3); };
+    const int t0off = tapoff(2 * g) * 8, t1off = tapoff(2 * g + 1) * 8; // first conv: lane group g holds taps 2g, 2g + 1
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        int q = t * 16 + nn;
+        int qq = q < HW ? q : HW - 1;
+        int y = qq / W, x = qq % W;
+        int base = ((y + 1) * (W + 1) + (x + 1) - TAP0);
+        aA[t] = base * SB + gh * SB + gl * 16;             // slices (3r, 3r + 1): + r (W + 1) SB
+        aB[t] = base * SB + gh * (W + 1) * SB + gl * 16;   // slice (2, 5): + 2 SB
+        aC[t] = base * SB + g * 8;                          // tap 8 (K = 16: channels 4g .. 4g + 3): + (2 (W + 1) + 2) SB
+        aO[t] = (base + TAP0) * SB + g * 8;                 // this lane's 4 output channels of its pixel, plane 0
+        iA[t] = base * 8;
+    }
+    wave_lds_handover();
+    NSTAMP(0);
+    f32x4 acc[NT], sk[NT];
+    // ---- first conv: K = (tap, 4 planes); inputs in one bf16 plane, weights in three ---------------------------------
+    {
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = bias0;
+        bf16x8 b[NT];
+        s16x4 b8[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            u32x2 lo = *(const u32x2 *)(inp + iA[t] + t0off), hi = *(const u32x2 *)(inp + iA[t] + t1off);
+            u32x4 both = {lo[0], lo[1], hi[0], hi[1]};
+            b[t] = __builtin_bit_cast(bf16x8, both);
+            b8[t] = __builtin_bit_cast(s16x4, *(const u32x2 *)(inp + iA[t] + tapoff(8) * 8));
+        }
+#pragma unroll
+        for (int q = 2; q >= 0; q--) // small terms first
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[q], b[t], acc[t], 0, 0, 0);
+        x3_mfma_switch();
+#pragma unroll
+        for (int q = 2; q >= 0; q--)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0b[q], b8[t], acc[t], 0, 0, 0);
+        x3_mfma_switch();
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; r++) y[r] = fmaxf(__builtin_fmaf(acc[t][r], scale0[r], shift0[r]), 0.f);
+            sk[t] = y;
+            u32x2 p1, p2, p3;
+            x3_split4(y, p1, p2, p3);
+            *(u32x2 *)(X + aO[t]) = p1;
+            *(u32x2 *)(X + aO[t] + 32) = p2;
+            *(u32x2 *)(X + aO[t] + 64) = p3;
+        }
+    }
+    if (nd.dbg & 64) { // debug: first conv output channel 0 of pixel `pos0 % HW`... lane 0 holds pixel 0 channels 0..3
+        if (lane == 0 && value_out) value_out[OI(pos0)] = sk[0][0];
+        return;
+    }
+    wave_lds_handover();
+    NSTAMP(1);
+    // ---- residual tower ------------------------------------------------------------------------------------------------
+    const int R_eff = (nd.dbg & 2) ? 0 : nd.R;
+    const int L = 2 * R_eff;
+    auto conv_layer = [&](const int l, auto skip_tag, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool SKIP = decltype(skip_tag)::value, LAST = decltype(last_tag)::value;
+        const float *ep = nd.epi + (size_t)(1 + l) * 48;
+        const unsigned char *wp = x3.wt + (size_t)l * XG::LAYER_B;
+        const f32x4 bias = *(const f32x4 *)(ep + 4 * g), scale = *(const f32x4 *)(ep + 16 + 4 * g),
+                    shift = *(const f32x4 *)(ep + 32 + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = bias;
+        // slice s: 0,1,2 = taps (3s, 3s + 1) at row s; 3 = taps (2, 5); then tap 8 (K = 16 instructions).
+        // A network wave is alone on its SIMD most of the time, so it hides its own LDS round trips.  Operands roll through
+        // the registers plane by plane: while the 3 NT MFMAs that use the pixels' first plane run (w3 x1, w2 x1, w1 x1 for
+        // every tile), the second plane arrives; during its 2 NT MFMAs the third plane, the next slice's weights and its
+        // first plane arrive -- a third of the registers of a whole-slice double buffer (which measured slower: spills).
+        auto xoff = [&](int s, int t) __attribute__((always_inline)) { return s < 3 ? aA[t] + s * (W + 1) * SB : aB[t] + 2 * SB; };
+        constexpr int T8 = (2 * (W + 1) + 2) * SB;
+        bf16x8 wc[3], wn[3], x0[NT], x1[NT], x2[NT];
+        s16x4 w8[3], y0[NT], y1[NT], y2[NT];
+#pragma unroll
+        for (int q = 0; q < 3; q++) wc[q] = *(const bf16x8 *)(wp + ((0 * 3 + q) * 64 + lane) * 16);
+#pragma unroll
+        for (int t = 0; t < NT; t++) x0[t] = *(const bf16x8 *)(X + xoff(0, t));
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) x1[t] = *(const bf16x8 *)(X + xoff(s, t) + 32);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 2; q >= 0; q--)
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[q], x0[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) x2[t] = *(const bf16x8 *)(X + xoff(s, t) + 64);
+            if (s + 1 < 4) {
+#pragma unroll
+                for (int q = 0; q < 3; q++) wn[q] = *(const bf16x8 *)(wp + (((s + 1) * 3 + q) * 64 + lane) * 16);
+#pragma unroll
+                for (int t = 0; t < NT; t++) x0[t] = *(const bf16x8 *)(X + xoff(s + 1, t));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; q++) w8[q] = *(const s16x4 *)(wp + 4 * 3 * 64 * 16 + (q * 64 + lane) * 8);
+#pragma unroll
+                for (int t = 0; t < NT; t++) y0[t] = *(const s16x4 *)(X + aC[t] + T8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 1; q >= 0; q--)
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[q], x1[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], x2[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < 4) {
+#pragma unroll
+                for (int q = 0; q < 3; q++) wc[q] = wn[q];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            y1[t] = *(const s16x4 *)(X + aC[t] + T8 + 32);
+            y2[t] = *(const s16x4 *)(X + aC[t] + T8 + 64);
+        }
+        x3_mfma_switch();
+#pragma unroll
+        for (int q = 2; q >= 0; q--)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w8[q], y0[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int q = 1; q >= 0; q--)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w8[q], y1[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w8[0], y2[t], acc[t], 0, 0, 0);
+        x3_mfma_switch();
+        wave_lds_handover(); // every lane's reads of X are done (their results feed the MFMAs above) before X is rewritten
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = __builtin_fmaf(acc[t][r], scale[r], shift[r]);
+                if constexpr (SKIP) v = v + sk[t][r];
+                y[r] = fmaxf(v, 0.f);
+            }
+            if constexpr (SKIP) sk[t] = y;
+            if constexpr (LAST) {
+                *(f32x4 *)(X + aO[t] + g * 8) = y; // float32 [slot][16 ch]: channels 4g .. 4g + 3 at byte 16 g of the slot
+            } else {
+                u32x2 p1, p2, p3;
+                x3_split4(y, p1, p2, p3);
+                *(u32x2 *)(X + aO[t]) = p1;
+                *(u32x2 *)(X + aO[t] + 32) = p2;
+                *(u32x2 *)(X + aO[t] + 64) = p3;
+            }
+        }
+        wave_lds_handover();
+    };
+    for (int blk = 0; blk < R_eff; blk++) {
+        conv_layer(2 * blk, std::false_type{}, std::false_type{});
+        if (blk + 1 < R_eff) conv_layer(2 * blk + 1, std::true_type{}, std::false_type{});
+        else conv_layer(2 * blk + 1, std::true_type{}, std::true_type{});
+    }
+    (void)L;
+    NSTAMP(2);
+    // ---- heads: pixel p on lane p ---------------------------------------------------------------------------------------
+    const float *hp = nd.head;
+    const float *vk = hp + nd.off_vk, *v3 = hp + nd.off_v3, *pk = hp + nd.off_pk, *p6 = hp + nd.off_p6;
+    float x = 0.f, x0 = 0.f, x1 = 0.f;
+    if (lane < HW) {
+        const int y_ = lane / W, x_ = lane % W;
+        const float *xp = (const float *)(X + ((y_ + 1) * (W + 1) + (x_ + 1)) * SB);
+        float av = v3[0], a0 = p6[0], a1 = p6[1];
+        if (R_eff == 0) { // no tower: the first conv's output is still in its three planes
+            const unsigned short *hpix = (const unsigned short *)xp;
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                float xv = __uint_as_float((unsigned)hpix[c] << 16) + __uint_as_float((unsigned)hpix[16 + c] << 16) +
+                           __uint_as_float((unsigned)hpix[32 + c] << 16);
+                av = __builtin_fmaf(xv, vk[c], av);
+                a0 = __builtin_fmaf(xv, pk[2 * c], a0);
+                a1 = __builtin_fmaf(xv, pk[2 * c + 1], a1);
+            }
+        } else {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++) {
+                f32x4 xv = *(const f32x4 *)(xp + 4 * c4);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int c = 4 * c4 + r;
+                    av = __builtin_fmaf(xv[r], vk[c], av);
+                    a0 = __builtin_fmaf(xv[r], pk[2 * c], a0);
+                    a1 = __builtin_fmaf(xv[r], pk[2 * c + 1], a1);
+                }
+            }
+        }
+        x = fmaxf(__builtin_fmaf(av, v3[1], v3[2]), 0.f);
+        x0 = fmaxf(__builtin_fmaf(a0, p6[2], p6[4]), 0.f);
+        x1 = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
+    }
+    NSTAMP(3);
+    head_one<G>(nd, pooled_sum(x), pooled_sum(x0), pooled_sum(x1), live ? OI(pos0) : 0, live, game_id, serial, noise, value_out,
+                logits_out, policy_out, pstride, nullptr);
+    NSTAMP(4);
+}
+
+// bb_net_eval / lock-step and asynchronous-round search: one position per wave, four waves per workgroup, the packed
+// weights streamed from L2
+template <class G>
+__global__ void __launch_bounds__(256) k_net_x3(NetDev nd, NetX3 x3, int n, const int *n_ptr, const int *slot_list, const typename G::State *states,
+                                                const int8_t *planes, const uint32_t *game_id, const int32_t *serial, int noise,
+                                                float *value_out, float *logits_out, float *policy_out, int pstride) {
+    using XG = X3Geom<G>;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * XG::WAVE_BYTES];
+    const int wave = threadIdx.x >> 6;
+    const int pos0 = blockIdx.x * 4 + wave;
+    if (n_ptr) n = *n_ptr; // compacted batch of an asynchronous round: the leaves posted this round, slots in slot_list
+    if (pos0 >= n) return;
+    net_body_x3<G, false>(nd, x3, n, pos0, slot_list, lds + wave * XG::WAVE_BYTES, states, planes, game_id, serial, noise, value_out,
+                          logits_out, policy_out, pstride, true);
+}

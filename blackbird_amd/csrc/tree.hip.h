@@ -803,13 +803,20 @@ __global__ void __launch_bounds__(256) k_selfplay_move(TreeDev d) {
 // Per game the sequence of simulations is exactly the sequential one, so results do not depend on the
 // schedule (tests/test_gpu_mcts.py: self-play == oracle, example by example).
 template <class G>
-__device__ bool async_game(const TreeDev &d, int g, int lane) {
+__device__ bool async_game(const TreeDev &d, int g, int lane
+#ifdef BB_STAMPS_LIGHT
+                           , int &g_light_loop, int &g_light_levels, int &g_light_load, int &g_light_puct
+#endif
+) {
     using Node = DenseNode<G>;
     constexpr int S = G::S, A = G::A;
     if (d.game_lid[g] < 0) return false;
     Node *pool = (Node *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
 #ifdef BB_STAMPS_DEEP
     long long sa0 = clock64(), s_apply = 0, s_level = 0, s_backup = 0, s_move = 0;
+#endif
+#ifdef BB_STAMPS_LIGHT
+    int lt_in = (int)clock64(), lt_loop = 0, ln_levels = 0, lt_create = 0, lt_puct = 0;
 #endif
     if (d.pend_leaf[g] >= 0) {
         phase_apply<G>(d, g, lane);
@@ -849,12 +856,23 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
         enum { F_PARKED = 2, F_LEAF = 4, F_TERM = 8, F_EXPAND = 16, F_OVERFLOW = 32 };
         int fl = 0;
         int pf_touch = 0; // speculative touch of the likeliest child's row (BB_PREFETCH_BEST)
+#ifdef BB_STAMPS_LIGHT
+        int lt_e = (int)clock64();
+#endif
         for (;;) {
             if (budget <= 0) { fl |= F_PARKED; break; }
             budget--;
+#ifdef BB_STAMPS_LIGHT
+            ln_levels++;
+#ifndef BB_STAMPS_LIGHT2
+            int lt_a = (int)clock64();
+#endif
+#endif
 #ifdef BB_STAMPS_DEEP
-            long long ts0 = clock64();
             st_levels++;
+#ifdef BB_STAMPS_PERLEVEL
+            long long ts0 = clock64();
+#endif
 #endif
             Node *node = pool + cur;
             typename G::State st_l = node->st;
@@ -867,8 +885,12 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
             int ci = node->child[lane];
             double cached = node->pad0;
             asm volatile("" ::"v"(flags_l), "v"(mask), "v"(sq), "v"(Ni), "v"(Qi), "v"(cPi), "v"(ci), "v"(pf_touch)); // (the previous level's touch is older than these loads)
-#ifdef BB_STAMPS_DEEP
+#if defined(BB_STAMPS_DEEP) && defined(BB_STAMPS_PERLEVEL)
             st_load += clock64() - ts0;
+#endif
+#if defined(BB_STAMPS_LIGHT) && !defined(BB_STAMPS_LIGHT2)
+            int lt_b = (int)clock64(); // the row has arrived (the asm above made the loads' results live)
+            lt_create += lt_b - lt_a;
 #endif
             st = st_l;
             flags = flags_l;
@@ -881,10 +903,16 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
                         long long sb0 = clock64();
 #endif
                         float v01 = (float)cached;
+#ifdef BB_STAMPS_LIGHT2
+                        int lt_k = (int)clock64();
+#endif
                         __threadfence_block(); // path stores of this descent
                         backup_path<G>(d, g, lane, pool, depth, v01, gs_prev(st));
                         if (lane == 0) d.sims_left[g] -= 1;
                         __threadfence_block();
+#ifdef BB_STAMPS_LIGHT2
+                        lt_puct += (int)clock64() - lt_k;
+#endif
                         sims_done++;
                         depth_sum += depth;
                         term_hits++;
@@ -917,11 +945,22 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
             double u = puct_score(child_q(d, Qi, 0.f, Ni), cPi, sq, Ni, lane < A && ((mask >> lane) & 1u));
             int child = ci;
             int a = grp_argmax<S>(u, lane, child);
+#if defined(BB_STAMPS_LIGHT) && !defined(BB_STAMPS_LIGHT2)
+            asm volatile("" ::"v"(a), "v"(child));
+            lt_puct += (int)clock64() - lt_b;
+#endif
             if (lane == 0) path[depth] = ((uint32_t)cur << 6) | ((uint32_t)((flags >> 4) & 3) << 4) | (uint32_t)a;
             if (child == CHILD_NONE) {
                 typename G::State st2;
                 bool terminal;
+#ifdef BB_STAMPS_LIGHT2
+                int lt_c = (int)clock64();
+#endif
                 child = create_child<G>(d, g, pool, node, st, a, lane, nn, st2, terminal);
+#ifdef BB_STAMPS_LIGHT2
+                asm volatile("" ::"v"(child));
+                lt_create += (int)clock64() - lt_c;
+#endif
                 if (child == CHILD_NONE) { fl |= F_OVERFLOW | F_LEAF; break; }
                 // the node just created is the leaf of this descent (never expanded, never cached): finish here instead of
                 // going round the loop once more to read back the row that was written a moment ago
@@ -935,6 +974,9 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
             depth++;
             cur = child & ~CHILD_TERM_BIT;
         }
+#ifdef BB_STAMPS_LIGHT
+        lt_loop += (int)clock64() - lt_e;
+#endif
         if (lane == 0) {
             d.resume_cur[g] = (fl & F_PARKED) ? cur : -1;
             d.resume_depth[g] = (fl & F_PARKED) ? depth : 0;
@@ -972,6 +1014,13 @@ __device__ bool async_game(const TreeDev &d, int g, int lane) {
         atomicAdd(&d.stamps[12], 1ull);
     }
 #endif
+#ifdef BB_STAMPS_LIGHT
+    g_light_loop = lt_loop;
+    g_light_load = lt_create;
+    g_light_puct = lt_puct;      // read back by the caller, which reduces over the wave (mega2.hip.h)
+    g_light_levels = ln_levels;
+    (void)lt_in;
+#endif
     if (lane == 0 && sims_done) {
         uint64_t *c = d.ctr + (size_t)g * 8;
         c[0] += (uint64_t)sims_done;
@@ -988,7 +1037,23 @@ __global__ void __launch_bounds__(256) k_tree_async(TreeDev d, int round) {
     int wv = t >> 6, l64 = t & 63;
     int g = wv * d.gpw + l64 / S, lane = l64 % S;
     bool live = l64 < d.gpw * S && g < d.n_slots;
+#ifdef BB_STAMPS_LIGHT
+    int ll = 0, lv = 0, lld = 0, lpu = 0;
+    bool posted = live ? async_game<G>(d, g, lane, ll, lv, lld, lpu) : false;
+    {
+        int m = lv;
+        for (int o = 32; o; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+        unsigned long long who = __ballot(live && lane == 0 && lv == m);
+        if (who && l64 == (int)__builtin_ctzll(who) && d.stamps) {
+            atomicAdd(&d.stamps[6], (unsigned long long)ll);
+            atomicAdd(&d.stamps[7], (unsigned long long)lv);
+            atomicAdd(&d.stamps[11], (unsigned long long)lld);
+            atomicAdd(&d.stamps[12], (unsigned long long)lpu);
+        }
+    }
+#else
     bool posted = live ? async_game<G>(d, g, lane) : false;
+#endif
     // wave-aggregated append to the round's compacted leaf list
     unsigned long long m = __ballot(posted && lane == 0);
     if (t == 0) d.post_count[(round + 2) & 3] = 0; // recycled two rounds from now

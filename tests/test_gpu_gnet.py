@@ -48,21 +48,29 @@ def test_c5_shape_vs_oracle(orc):
 
 
 def test_general_path_equals_fused_path_at_16_filters(monkeypatch):
+    """The general-filter kernels and the fused float32-MFMA tower are the same k-ordered fmaf chains: identical bits.  The
+    default 16-filter path of the dense games runs on the bf16 matrix pipe with three-way split operands (net_x3.hip.h):
+    float32 products, another summation order -- within the 1e-5 of the north star, not bit-identical."""
     game = _lib.GAME_CONNECT4
     gi = _lib.game_info(game)
     flat = W.flatten(W.init_weights(gi.C, 16, 4, 16, gi.A, seed=3, perturb=True))
     rng = np.random.RandomState(0)
     b, pl = boards_for(game, rng, 77)
     st = _lib.pack_grid(game, b, pl)
-    outs = []
-    for force in ("0", "1"):
-        monkeypatch.setenv("BB_GNET", force)
+    outs = {}
+    for name, gnet, x3 in (("fused f32", "0", "0"), ("general", "1", "0"), ("fused x3", "0", "1")):
+        monkeypatch.setenv("BB_GNET", gnet)
+        monkeypatch.setenv("BB_NET_X3", x3)
         eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET, noise_on=True)
         eng.load_weights(flat)
-        outs.append(eng.net_eval(states=st))
+        outs[name] = eng.net_eval(states=st)
         eng.close()
-    for a, b2 in zip(*outs):
+    for a, b2 in zip(outs["fused f32"], outs["general"]):
         assert np.array_equal(a, b2)
+    v, l, p = outs["fused f32"]
+    v3, l3, p3 = outs["fused x3"]
+    assert np.max(np.abs(v3 - v)) <= 1e-5 and np.max(np.abs(p3 - p)) <= 1e-5
+    assert np.max(np.abs(l3 - l) / np.maximum(1.0, np.abs(l))) <= 1e-5
 
 
 def test_dragonchess_general_filters(orc):

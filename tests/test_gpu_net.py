@@ -1,6 +1,8 @@
 """-m gpu: the fused MFMA tower + heads (through the C ABI) vs the oracle's float32 restatement.
-Tolerance 1e-5 on value / logits / policy (BASELINE.json north_star); the tower itself is expected
-to be bit-identical (MFMA f32 == k-ordered fmaf chain), differences come from expf/tanhf only."""
+Tolerance 1e-5 on value / logits / policy (BASELINE.json north_star).  The float32-MFMA tower (BB_NET_X3=0, and every
+DragonChess / general-filter network) is bit-identical to the oracle's k-ordered fmaf chains; the default tower of the dense
+games runs on the bf16 matrix pipe with three-way split operands (exact float32 products, the MFMA's own summation order):
+measured 3e-6 relative on logits, 6e-7 on values."""
 import numpy as np
 import pytest
 
@@ -23,7 +25,9 @@ def boards_for(game, rng, n):
 @pytest.mark.parametrize("game,og", [(_lib.GAME_CONNECT4, 0), (_lib.GAME_TICTACTOE, 1)])
 @pytest.mark.parametrize("perturb", [False, True])
 @pytest.mark.parametrize("n", [1, 5, 16, 203])
-def test_net_vs_oracle(orc, game, og, perturb, n):
+@pytest.mark.parametrize("x3", ["1", "0"])
+def test_net_vs_oracle(orc, monkeypatch, game, og, perturb, n, x3):
+    monkeypatch.setenv("BB_NET_X3", x3)
     gi = _lib.game_info(game)
     w = W.init_weights(gi.C, 16, 4, 16, gi.A, seed=11, perturb=perturb)
     flat = W.flatten(w)
@@ -42,7 +46,8 @@ def test_net_vs_oracle(orc, game, og, perturb, n):
     assert np.max(np.abs(l1 - ol) / np.maximum(1.0, np.abs(ol))) <= TOL
     assert np.max(np.abs(p1 - op)) <= TOL
     print(f"bit-exact logits: {np.mean(l1 == ol):.3f}, value: {np.mean(v1 == ov):.3f}")
-    assert np.mean(l1 == ol) > 0.99  # k-ordered MFMA chain == oracle fmaf chain
+    if x3 == "0":
+        assert np.mean(l1 == ol) > 0.99  # k-ordered f32 MFMA chain == oracle fmaf chain
     # batch invariance: a position's outputs do not depend on where it sits in the batch
     perm = rng.permutation(n)
     v3, l3, p3 = eng.net_eval(states=st[perm])
@@ -171,11 +176,13 @@ def test_empty_and_single_position_batches():
 
 
 @pytest.mark.parametrize("game,og", [(_lib.GAME_CONNECT4, 0), (_lib.GAME_TICTACTOE, 1)])
-def test_every_positions_per_wave_variant_matches_oracle(orc, game, og):
+def test_every_positions_per_wave_variant_matches_oracle(orc, monkeypatch, game, og):
     """The fused kernel is instantiated for 1, 2 and the LDS-filling number of positions per wave (12 for TicTacToe, 4 for
     Connect4), picked by batch size; the tile counts (1, 2, 7 / 3, 6, 11 tiles of 16 pixels) go through different operand
     schedules.  All of them against the oracle, logits bit-identical.  (Round 2 found a compiler reordering across the
-    cross-lane LDS hand-over between layers that only struck the one-tile variant: net.hip.h wave_lds_handover.)"""
+    cross-lane LDS hand-over between layers that only struck the one-tile variant: net.hip.h wave_lds_handover.)
+    These are the float32-MFMA kernels (BB_NET_X3=0); the bf16-pipe form has one position per wave at every batch size."""
+    monkeypatch.setenv("BB_NET_X3", "0")
     gi = _lib.game_info(game)
     flat = W.flatten(W.init_weights(gi.C, 16, 4, 16, gi.A, seed=2, perturb=True))
     eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)

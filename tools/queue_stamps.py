@@ -22,11 +22,17 @@ print(f"3 plies in {dt*1e3:.1f} ms")
 print(f"wave lifetimes (mean over waves, shader cycles / 2.4e6 = ms): network {st[1]/max(st[4],1)/2.4e6:.1f} ms, tree {st[3]/max(st[5],1)/2.4e6:.1f} ms of a {dt*1e3:.1f} ms run"); print(f"net waves: busy {st[0]/st[1]:.3f}; cycles per evaluation {st[0]/st[15]:.0f}; evaluations {st[15]:.0f}")
 print(f"tree waves: busy {st[2]/st[3]:.3f}; cycles per async call {st[2]/st[13]:.0f}; games per call {st[14]/st[13]:.2f}; calls {st[13]:.0f}")
 v = st[12]
-if v > 0 and os.environ.get("QMODE", "1") == "1":
+if v > 0 and os.environ.get("LIGHT"):
+    print(f"LIGHT: async_game {st[11]/v:.0f} cycles per game-visit; longest game of each call: {st[6]/max(st[7],1):.0f} cycles per level in its descent loops")
+elif v > 0 and os.environ.get("QMODE", "1") == "1":
     print(f"DEEP per game-visit cycles: total {st[11]/v:.0f} apply {st[8]/v:.0f} cached-backups {st[9]/v:.0f} move {st[10]/v:.0f} load-wait {st[6]/v:.0f}; levels/visit {st[7]/v:.2f}")
 clk = 2.4e3  # shader cycles per us (approx); wall clock ticks are 100 MHz
 print(f"per evaluation: queue wait {st[10]/st[15]/100:.1f} us, network {st[0]/st[15]/clk:.1f} us; result pick-up wait {st[8]/max(st[9],1)/100:.1f} us; tree call {st[2]/st[13]/clk:.1f} us")
 L.bb_debug_net_stamps(eng.h, ns.ctypes.data); ns = ns.astype(np.float64)
+if os.environ.get("NETSTAMPS"):
+    e = st[15]
+    print("network wave, cycles per evaluation: prologue %.0f, first conv %.0f, tower %.0f, head convs %.0f, value/policy/noise %.0f, apply (expand + backup) %.0f"
+          % tuple(ns[i] / e for i in range(6)))
 if os.environ.get("QMODE") == "2":
     passes = st[11]
     ns = ns / passes
