@@ -44,6 +44,8 @@ from blackbird_amd import _lib, weights as W  # noqa: E402
 
 FLOPS_PER_EVAL_C2 = 1_588_700  # SURVEY.md 8d / BASELINE.md: C2 network, conv + heads
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_16x16x32_bf16, 16 cycles per SIMD)
+X3_PRODUCTS = 6                # bf16 MFMA products per float32 product of the split-operand tower (net_x3.hip.h)
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec (6290 measured copy)
 
 WORKLOADS = {
@@ -311,14 +313,17 @@ def main():
     if rank == 0:
         mode = eng.selfplay_mode()
         gname = {"c2": "Connect4", "c5": "Connect4", "dc": "DragonChess"}[args.workload]
-        if mode == 3:
+        form = eng.net_form()
+        if mode == 3 and form == 2:
+            kernel = f"k_selfplay_queue<{gname},8,x3> (8 network + 4 tree waves per CU, LDS work queue; tower on the bf16 matrix pipe, float32 by 3-way operand split)"
+        elif mode == 3:
             kernel = f"k_selfplay_queue<{gname},8> (8 network + 4 tree waves per CU, LDS work queue)"
         elif mode == 5:
             kernel = "k_dc_selfplay_fused (one wave per game: tree step, network and move in the same wave)"
         elif w["filters"] != 16:
             kernel = "k_gnet_conv<%s,false,4,2> x %d conv layers + first conv + heads per evaluation batch" % (gname, 2 * w["blocks"])
         else:
-            kernel = f"k_net_compact<{gname},4>" if mode == 1 else f"k_net_fused16<{gname}>"
+            kernel = (f"k_net_x3<{gname}>" if form == 2 else f"k_net_compact<{gname},4>" if mode == 1 else f"k_net_fused16<{gname}>")
         if mode >= 2:
             # persistent kernel: a launch covers up to 16 steps; its FLOPs are the evaluations it performed
             launches = max(net_n, 1)
@@ -328,6 +333,10 @@ def main():
             flops_per_launch = fpe * cnt["evals"] / max(K * sims, 1)
             sims_per_launch = cnt["sims"] / max(K * sims, 1)
         achieved = flops_per_launch / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
+        # The roof of the arithmetic actually issued.  float32 MFMA forms: the f32 MFMA peak.  Split-operand form: every
+        # float32 product is six bf16 MFMA products, so the ceiling for float32-equivalent FLOP/s is the bf16 peak / 6
+        # (416.7 TFLOP/s); `achieved` stays the ALGORITHMIC float32 FLOPs of SURVEY.md 8d either way.
+        peak = PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS if form == 2 else PEAK_F32_MFMA_TFLOPS
         mean_depth = cnt["sum_depth"] / max(cnt["sims"], 1)
         a_c = 7.0 if gname == "Connect4" else 14.6   # DragonChess: mean legal count of SURVEY.md 6 [probe]
         b_sim = tree_bytes_per_sim(w, mean_depth, a_c)
@@ -339,7 +348,8 @@ def main():
         out = {
             "metric": "selfplay_games_per_sec", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / max(K, 1) * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (float32 operands split exactly into 3 bf16 values, 6 bf16 MFMA products each, f32 accumulate)" if form == 2 else "f32",
             "data": "synthetic (self-play from the initial position, random-init weights seed 0)",
             "config": {"workload": "%s, DynamicMCTS %d sims/move, %d concurrent games per GPU, net R%d/F%d/D16 fp32, "
                                    "noise alpha 0.2 eps 0.3 (BASELINE configs[%d])"
@@ -359,7 +369,11 @@ def main():
             "terminal_leaf_fraction": cnt["terminal_leaves"] / max(cnt["sims"], 1),
             "mean_leaf_depth": mean_depth, "overflow": cnt["overflow"],
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "peak_note": ("bf16 MFMA dense peak 2500 / 6 products per float32 product; against the float32 MFMA "
+                                       "peak (157.3) the same algorithmic rate is %.3f" % (achieved / PEAK_F32_MFMA_TFLOPS))
+                                      if form == 2 else "float32 MFMA dense peak",
+                         "bf16_tflops_issued": (achieved * X3_PRODUCTS * 48.0 / 42.0) if (form == 2 and gname == "Connect4") else None,
                          "traffic": (traffic_rate * net_ms * 1e-3) if (mode >= 2 and traffic_rate) else None,
                          "traffic_note": ("HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) rate from profiles/%s x this "
                                           "launch's duration" % traffic_src) if traffic_src else "no PMC pass committed for this workload",

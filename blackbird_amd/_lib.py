@@ -20,7 +20,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_NAN, ERR_CAPACITY, ERR_WEIGHTS = 0, -1, -2,
 EXPORTS = (
     "bb_game_info_get", "bb_last_error", "bb_device_count", "bb_game_legal", "bb_game_apply", "bb_game_winner",
     "bb_game_encode", "bb_game_initial", "bb_create", "bb_destroy", "bb_load_weights", "bb_get_counters",
-    "bb_reset_counters", "bb_synchronize", "bb_set_sims_per_move", "bb_timing_enable", "bb_timing_read", "bb_timing_net", "bb_selfplay_mode", "bb_net_eval", "bb_hash_eval", "bb_set_roots", "bb_run_sims", "bb_run_sims_masked",
+    "bb_reset_counters", "bb_synchronize", "bb_set_sims_per_move", "bb_timing_enable", "bb_timing_read", "bb_timing_net", "bb_selfplay_mode", "bb_net_form", "bb_net_eval", "bb_hash_eval", "bb_set_roots", "bb_run_sims", "bb_run_sims_masked",
     "bb_sample_moves", "bb_move_roots", "bb_get_root_states", "bb_selfplay_begin", "bb_selfplay_step",
     "bb_selfplay_done", "bb_examples_fetch", "bb_examples_device", "bb_net_eval_keyed", "bb_set_rng_stream", "bb_fit_slots",
 )
@@ -89,6 +89,7 @@ def lib():
     L.bb_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ip)]
     L.bb_timing_net.argtypes = [vp, ip, ip, ip, C.POINTER(C.c_double)]
     L.bb_selfplay_mode.argtypes = [vp]
+    L.bb_net_form.argtypes = [vp]
     L.bb_net_eval.argtypes = [vp, ip, vp, vp, vp, vp, vp, ip]
     L.bb_net_eval_keyed.argtypes = [vp, ip, vp, vp, vp, vp, vp, vp, vp]
     L.bb_set_rng_stream.argtypes = [vp, C.c_uint64, C.c_uint32]
@@ -338,6 +339,10 @@ class Engine:
 
     def selfplay_mode(self):
         return check(lib().bb_selfplay_mode(self.h))
+
+    def net_form(self):
+        """0 float32-MFMA fused tower, 1 general-filter launches, 2 float32 results on the bf16 matrix pipe (bb_net_form)."""
+        return check(lib().bb_net_form(self.h))
 
     def timing_net(self, iters=50, noise=True, ablate=0):
         ms = C.c_double()

@@ -187,7 +187,7 @@ struct bb_engine {
     DCEdges edges; // DragonChess only
     int32_t *d_child_action = nullptr;
     NetDev net;
-    NetX3 x3 = {nullptr, nullptr}; // 16-filter network of a dense game on the bf16 matrix pipe (net_x3.hip.h); null: float32 MFMA path
+    NetX3 x3 = {nullptr, nullptr, nullptr}; // 16-filter network of a dense game on the bf16 matrix pipe (net_x3.hip.h); null: float32 MFMA path
     size_t x3_bytes = 0;
     bool has_weights = false;
     int net_F = 0, net_C = 0;
@@ -500,6 +500,12 @@ extern "C" int bb_timing_read(bb_engine *e, double *mean_ms_out, double *min_ms_
     return BB_OK;
 }
 
+extern "C" int bb_net_form(bb_engine *e) {
+    if (!e) return fail(BB_ERR_ARG, "null engine");
+    if (!e->has_weights) return fail(BB_ERR_WEIGHTS, "bb_load_weights has not been called");
+    return e->general_net ? 1 : (e->x3.w0 ? 2 : 0);
+}
+
 extern "C" int bb_selfplay_mode(bb_engine *e) {
     if (!e) return fail(BB_ERR_ARG, "null engine");
     // the persistent kernels carry a 16-filter network of at most MEGA_RMAX blocks in LDS; anything else runs as rounds
@@ -663,13 +669,16 @@ static void bf16_split3(float v, uint16_t out[3]) {
     r = r - bf16_value(out[1]);
     out[2] = bf16_rne(r);
 }
-// w0: [plane][lane][8] (taps 2g, 2g + 1 x 4 input planes) then [plane][lane][4] (tap 8, lane group 0 only)
-// wt: per layer [slice 0..3][plane][lane][8] (slices = taps (0,1), (3,4), (6,7), (2,5); lane group g: tap g >> 1 of the
-//     slice, channels 8 (g & 1) .. + 7) then [plane][lane][4] (tap 8, channels 4g .. 4g + 3)
-static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vector<uint16_t> &wt) {
+// w0:   [plane][lane][8] (taps 2g, 2g + 1 x 4 input planes) then [plane][lane][4] (tap 8, lane group 0 only)
+// wt12: per layer [slice 0..3][plane 0..1][lane][8] (slices = taps (0,1), (3,4), (6,7), (2,5); lane group g: tap g >> 1 of the
+//       slice, channels 8 (g & 1) .. + 7) then [plane 0..1][lane][4] (tap 8, channels 4g .. 4g + 3)
+// wt3:  per layer [slice][lane][8] then [lane][4]: the third plane alone
+static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vector<uint16_t> &wt12, std::vector<uint16_t> &wt3) {
     const int F = 16, C = w->C, R = w->R;
     w0.assign((3 * 64 * 8 + 3 * 64 * 4), 0);
-    wt.assign((size_t)2 * R * (4 * 3 * 64 * 8 + 3 * 64 * 4), 0);
+    const size_t per12 = 4 * 2 * 64 * 8 + 2 * 64 * 4, per3 = 4 * 64 * 8 + 64 * 4;
+    wt12.assign((size_t)2 * R * per12, 0);
+    wt3.assign((size_t)2 * R * per3, 0);
     uint16_t h[3];
     for (int lane = 0; lane < 64; lane++) {
         const int f = lane & 15, g = lane >> 4;
@@ -684,20 +693,21 @@ static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vec
         }
     }
     static const int slice_taps[4][2] = {{0, 1}, {3, 4}, {6, 7}, {2, 5}};
-    const size_t per_layer = 4 * 3 * 64 * 8 + 3 * 64 * 4;
     for (int l = 0; l < 2 * R; l++) {
-        uint16_t *o = wt.data() + (size_t)l * per_layer;
+        uint16_t *o12 = wt12.data() + (size_t)l * per12, *o3 = wt3.data() + (size_t)l * per3;
         for (int lane = 0; lane < 64; lane++) {
             const int f = lane & 15, g = lane >> 4;
             for (int sl = 0; sl < 4; sl++)
                 for (int i = 0; i < 8; i++) {
                     int tap = slice_taps[sl][g >> 1], ch = 8 * (g & 1) + i;
                     bf16_split3(w->blk_k[(((size_t)l * 9 + tap) * F + ch) * F + f], h);
-                    for (int q = 0; q < 3; q++) o[(((size_t)sl * 3 + q) * 64 + lane) * 8 + i] = h[q];
+                    for (int q = 0; q < 2; q++) o12[(((size_t)sl * 2 + q) * 64 + lane) * 8 + i] = h[q];
+                    o3[((size_t)sl * 64 + lane) * 8 + i] = h[2];
                 }
             for (int i = 0; i < 4; i++) {
                 bf16_split3(w->blk_k[(((size_t)l * 9 + 8) * F + (4 * g + i)) * F + f], h);
-                for (int q = 0; q < 3; q++) o[(size_t)4 * 3 * 64 * 8 + ((size_t)q * 64 + lane) * 4 + i] = h[q];
+                for (int q = 0; q < 2; q++) o12[(size_t)4 * 2 * 64 * 8 + ((size_t)q * 64 + lane) * 4 + i] = h[q];
+                o3[(size_t)4 * 64 * 8 + (size_t)lane * 4 + i] = h[2];
             }
         }
     }
@@ -783,20 +793,22 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     {
         const bool want = F == 16 && C <= 4 && !e->general_net && !(getenv("BB_NET_X3") && atoi(getenv("BB_NET_X3")) == 0);
         if (want) {
-            std::vector<uint16_t> xw0, xwt;
-            pack_x3(w, xw0, xwt);
-            const size_t bytes = (xw0.size() + xwt.size()) * 2;
+            std::vector<uint16_t> xw0, xw12, xw3;
+            pack_x3(w, xw0, xw12, xw3);
+            const size_t b0 = xw0.size() * 2, b12 = xw12.size() * 2, b3 = xw3.size() * 2, bytes = b0 + b12 + b3;
             unsigned char *d_x = (unsigned char *)e->x3.w0;
             if (!d_x || bytes != e->x3_bytes) {
                 if (dalloc(e, d_x, bytes + 16, false)) return BB_ERR_HIP;
                 e->x3_bytes = bytes;
             }
-            HIPCHK(hipMemcpy(d_x, xw0.data(), xw0.size() * 2, hipMemcpyHostToDevice));
-            if (!xwt.empty()) HIPCHK(hipMemcpy(d_x + xw0.size() * 2, xwt.data(), xwt.size() * 2, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_x, xw0.data(), b0, hipMemcpyHostToDevice));
+            if (b12) HIPCHK(hipMemcpy(d_x + b0, xw12.data(), b12, hipMemcpyHostToDevice));
+            if (b3) HIPCHK(hipMemcpy(d_x + b0 + b12, xw3.data(), b3, hipMemcpyHostToDevice));
             e->x3.w0 = d_x;
-            e->x3.wt = d_x + xw0.size() * 2;
+            e->x3.wt12 = d_x + b0;
+            e->x3.wt3 = d_x + b0 + b12;
         } else {
-            e->x3.w0 = e->x3.wt = nullptr;
+            e->x3.w0 = e->x3.wt12 = e->x3.wt3 = nullptr;
         }
     }
     nd.R = R;
@@ -1227,8 +1239,19 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
             const int netw = getenv("BB_QUEUE_NETW") ? atoi(getenv("BB_QUEUE_NETW")) : 8; // network waves of the 12 (tuning)
             if (e->x3.w0) { // bf16-pipe network: 8 waves of 256 VGPRs -- Connect4 5 network + 3 tree waves, TicTacToe 4 + 4
                 if constexpr (G::S <= 8) {
-                    if (getenv("BB_QUEUE_NETW") && netw == 4) k_selfplay_queue<G, 4, true, 8><<<nb, 512, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim);
-                    else k_selfplay_queue<G, 5, true, 8><<<nb, 512, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim);
+                    const int waves = getenv("BB_QUEUE_WAVES") ? atoi(getenv("BB_QUEUE_WAVES")) : 12;
+                    const int nw = getenv("BB_QUEUE_NETW") ? netw : (waves == 12 ? 8 : 5);
+#define QX3(NW, WV) k_selfplay_queue<G, NW, true, WV><<<nb, WV * 64, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim)
+                    if (waves == 12) { // 8 network + 4 tree waves of 168 VGPRs (default); BB_QUEUE_WAVES=8: 5 + 3 (6 + 2) waves of 256
+                        if (nw == 6) QX3(6, 12);
+                        else if (nw == 7) QX3(7, 12);
+                        else QX3(8, 12);
+                    } else {
+                        if (nw == 4) QX3(4, 8);
+                        else if (nw == 6) QX3(6, 8);
+                        else QX3(5, 8);
+                    }
+#undef QX3
                 } else {
                     k_selfplay_queue<G, 4, true, 8><<<nb, 512, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim);
                 }

@@ -33,6 +33,9 @@
 #ifndef BB_NET_APPLIES
 #define BB_NET_APPLIES -1 // tuning override of NET_APPLIES (k_selfplay_queue): 1 network waves apply their result, 0 tree waves do
 #endif
+#ifndef BB_X3_LEAN
+#define BB_X3_LEAN 0 // net_x3.hip.h operand schedule of the persistent kernel: 0 = a phase ahead (38 spilled registers at 168, still faster), 1 = in place
+#endif
 #ifndef BB_QUEUE_WMODE
 #define BB_QUEUE_WMODE 2 // net.hip.h conv_layer: weights in LDS, next tap's operands requested ahead of this tap's MFMAs
 #endif
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
     using XG = X3Geom<G>;
     constexpr int EPI_F = (1 + 2 * RMAX) * 48, HEAD_F = MEGA_HEAD_FLOATS;
     // operand floats: float32 form [wt][w0], x3 form [w0 bytes][wt bytes]; then epilogue constants and head parameters
-    constexpr int WT_F = X3 ? 2 * RMAX * XG::LAYER_B / 4 : 2 * RMAX * 9 * 64 * 4, W0_F = X3 ? XG::W0_B / 4 : STEPS0 * 64;
+    constexpr int WT_F = X3 ? 2 * RMAX * XG::LAYER12_B / 4 : 2 * RMAX * 9 * 64 * 4, W0_F = X3 ? XG::W0_B / 4 : STEPS0 * 64;
     constexpr int WAVE_F = X3 ? XG::WAVE_BYTES / 4 : NG::WAVE_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[NETW * WAVE_F];
     __shared__ __attribute__((aligned(16))) float wlds[WT_F + W0_F + EPI_F + HEAD_F];
@@ -197,12 +200,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
     NetDev ndl = nd;
     NetX3 x3l = x3;
     {
-        const float *gwt = X3 ? (const float *)x3.wt : (const float *)nd.wt;
+        const float *gwt = X3 ? (const float *)x3.wt12 : (const float *)nd.wt;
         const float *gw0 = X3 ? (const float *)x3.w0 : nd.w0;
-        const int wt_used = X3 ? 2 * nd.R * XG::LAYER_B / 4 : 2 * nd.R * 9 * 64 * 4;
+        const int wt_used = X3 ? 2 * nd.R * XG::LAYER12_B / 4 : 2 * nd.R * 9 * 64 * 4;
         for (int i = threadIdx.x; i < wt_used; i += MEGA2_THREADS) wlds[i] = gwt[i];
         for (int i = threadIdx.x; i < W0_F; i += MEGA2_THREADS) wlds[WT_F + i] = gw0[i];
-        x3l.wt = (const unsigned char *)wlds;
+        x3l.wt12 = (const unsigned char *)wlds; // (x3l.wt3 stays in global memory)
         x3l.w0 = (const unsigned char *)(wlds + WT_F);
         for (int i = threadIdx.x; i < (1 + 2 * nd.R) * 48; i += MEGA2_THREADS) wlds[WT_F + W0_F + i] = nd.epi[i];
         for (int i = threadIdx.x; i < nd.head_floats; i += MEGA2_THREADS) wlds[WT_F + W0_F + EPI_F + i] = nd.head[i];
@@ -342,7 +345,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
             }
 #else
             if constexpr (X3)
-                net_body_x3<G, true>(ndl, x3l, 1, 0, &myslot[wave], (unsigned char *)wl, (const typename G::State *)d.leaf_state, nullptr,
+                net_body_x3<G, true, (BB_X3_LEAN != 0)>(ndl, x3l, 1, 0, &myslot[wave], (unsigned char *)wl, (const typename G::State *)d.leaf_state, nullptr,
                                      d.leaf_game_id, d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false);
             else
                 net_body<G, 1, BB_QUEUE_WMODE>(ndl, 1, 0, &myslot[wave], wl, (const typename G::State *)d.leaf_state, nullptr,

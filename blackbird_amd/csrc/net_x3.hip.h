@@ -45,14 +45,18 @@ struct X3Geom {
     static constexpr int INP_B = (SLOTS * 8 + 15) / 16 * 16;
     static constexpr int STATE_B = ((int)sizeof(typename G::State) + 15) / 16 * 16;
     static constexpr int WAVE_BYTES = X_B + INP_B + STATE_B;
-    // packed weights (bytes): a tower layer = 4 slices x 3 planes x 64 lanes x 16 B + tap 8: 3 planes x 64 lanes x 8 B
-    static constexpr int LAYER_B = 4 * 3 * 64 * 16 + 3 * 64 * 8;   // 13 824
-    static constexpr int W0_B = 3 * 64 * 16 + 3 * 64 * 8;          // first conv: taps 0..7 (K = 32) + tap 8 (K = 16)
+    // packed weights (bytes).  A tower layer's first two planes (4 slices x 2 planes x 64 lanes x 16 B + tap 8: 2 planes x 64
+    // lanes x 8 B) are what the persistent kernel keeps in LDS; the third plane (one product in six reads it) is a separate
+    // array that every kernel streams from L2, a layer ahead -- with all three planes in LDS only 5 network waves fit a CU.
+    static constexpr int LAYER12_B = 4 * 2 * 64 * 16 + 2 * 64 * 8; // 9 216
+    static constexpr int LAYER3_B = 4 * 64 * 16 + 64 * 8;          // 4 608
+    static constexpr int W0_B = 3 * 64 * 16 + 3 * 64 * 8;          // first conv: taps 0..7 (K = 32) + tap 8 (K = 16), 3 planes
 };
 
-struct NetX3 {           // device pointers of the packed operands (nullptr: this network has no x3 form)
-    const unsigned char *w0; // X3Geom::W0_B
-    const unsigned char *wt; // [2R] x LAYER_B
+struct NetX3 {             // device pointers of the packed operands (nullptr: this network has no x3 form)
+    const unsigned char *w0;   // X3Geom::W0_B
+    const unsigned char *wt12; // [2R] x LAYER12_B   planes 1 and 2 of the tower weights
+    const unsigned char *wt3;  // [2R] x LAYER3_B    plane 3, always read from global memory
 };
 
 __device__ __forceinline__ unsigned bf16_bits(float v) { // round to nearest even, as v_cvt_pk_bf16_f32 does for finite values
@@ -89,7 +93,10 @@ __device__ __forceinline__ void x3_split4(const f32x4 y, u32x2 &p1, u32x2 &p2, u
 }
 
 // WLDS: the packed weights (x3.w0 / x3.wt, nd.epi, nd.head) are in LDS (persistent kernel) -- else global (L2-resident).
-template <class G, bool WLDS>
+// LEAN: two network waves share each SIMD (12-wave persistent kernel, 168 VGPRs): the partner's MFMAs cover this wave's LDS
+// round trips, so operands are read tile by tile right where they are used instead of a phase ahead -- a third of the
+// operand registers.
+template <class G, bool WLDS, bool LEAN = false>
 __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, int n, int pos0, const int *slot_list,
                                             unsigned char *wl, const typename G::State *states, const int8_t *planes,
                                             const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
@@ -214,25 +221,78 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     // ---- residual tower ------------------------------------------------------------------------------------------------
     const int R_eff = (nd.dbg & 2) ? 0 : nd.R;
     const int L = 2 * R_eff;
+    // plane 3 of the tower weights comes from L2: the five operands of a layer are requested a layer ahead
+    bf16x8 w3c[4];
+    s16x4 w3c8;
+    if (L > 0) {
+#pragma unroll
+        for (int sl = 0; sl < 4; sl++) w3c[sl] = *(const bf16x8 *)(x3.wt3 + (sl * 64 + lane) * 16);
+        w3c8 = *(const s16x4 *)(x3.wt3 + 4 * 64 * 16 + lane * 8);
+    }
     auto conv_layer = [&](const int l, auto skip_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr bool SKIP = decltype(skip_tag)::value, LAST = decltype(last_tag)::value;
         const float *ep = nd.epi + (size_t)(1 + l) * 48;
-        const unsigned char *wp = x3.wt + (size_t)l * XG::LAYER_B;
-        const f32x4 bias = *(const f32x4 *)(ep + 4 * g), scale = *(const f32x4 *)(ep + 16 + 4 * g),
-                    shift = *(const f32x4 *)(ep + 32 + 4 * g);
+        const unsigned char *wp = x3.wt12 + (size_t)l * XG::LAYER12_B;
+        {
+            const f32x4 bias = *(const f32x4 *)(ep + 4 * g);
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = bias;
+            for (int t = 0; t < NT; t++) acc[t] = bias;
+        }
         // slice s: 0,1,2 = taps (3s, 3s + 1) at row s; 3 = taps (2, 5); then tap 8 (K = 16 instructions).
-        // A network wave is alone on its SIMD most of the time, so it hides its own LDS round trips.  Operands roll through
-        // the registers plane by plane: while the 3 NT MFMAs that use the pixels' first plane run (w3 x1, w2 x1, w1 x1 for
-        // every tile), the second plane arrives; during its 2 NT MFMAs the third plane, the next slice's weights and its
-        // first plane arrive -- a third of the registers of a whole-slice double buffer (which measured slower: spills).
+        // Operands roll through the registers plane by plane: while the 3 NT MFMAs that use the pixels' first plane run
+        // (w3 x1, w2 x1, w1 x1 for every tile), the second plane arrives; during its 2 NT MFMAs the third plane, the next
+        // slice's weights and its first plane arrive -- a third of the registers of a whole-slice double buffer (which
+        // measured slower: spills).
         auto xoff = [&](int s, int t) __attribute__((always_inline)) { return s < 3 ? aA[t] + s * (W + 1) * SB : aB[t] + 2 * SB; };
         constexpr int T8 = (2 * (W + 1) + 2) * SB;
-        bf16x8 wc[3], wn[3], x0[NT], x1[NT], x2[NT];
-        s16x4 w8[3], y0[NT], y1[NT], y2[NT];
+        if constexpr (LEAN) {
 #pragma unroll
-        for (int q = 0; q < 3; q++) wc[q] = *(const bf16x8 *)(wp + ((0 * 3 + q) * 64 + lane) * 16);
+            for (int s = 0; s < 4; s++) {
+                const bf16x8 wa = *(const bf16x8 *)(wp + ((s * 2 + 0) * 64 + lane) * 16), wb = *(const bf16x8 *)(wp + ((s * 2 + 1) * 64 + lane) * 16);
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const bf16x8 xa = *(const bf16x8 *)(X + xoff(s, t)), xb = *(const bf16x8 *)(X + xoff(s, t) + 32),
+                                 xc_ = *(const bf16x8 *)(X + xoff(s, t) + 64);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3c[s], xa, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xc_, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xa, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xa, acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const s16x4 va = *(const s16x4 *)(wp + 4 * 2 * 64 * 16 + (0 * 64 + lane) * 8), vb = *(const s16x4 *)(wp + 4 * 2 * 64 * 16 + (1 * 64 + lane) * 8);
+            s16x4 ya[NT], yb[NT], yc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                ya[t] = *(const s16x4 *)(X + aC[t] + T8);
+                yb[t] = *(const s16x4 *)(X + aC[t] + T8 + 32);
+                yc[t] = *(const s16x4 *)(X + aC[t] + T8 + 64);
+            }
+            const s16x4 w38 = w3c8;
+            if (l + 1 < L) {
+                const unsigned char *g3 = x3.wt3 + (size_t)(l + 1) * XG::LAYER3_B;
+#pragma unroll
+                for (int sl = 0; sl < 4; sl++) w3c[sl] = *(const bf16x8 *)(g3 + (sl * 64 + lane) * 16);
+                w3c8 = *(const s16x4 *)(g3 + 4 * 64 * 16 + lane * 8);
+            }
+            x3_mfma_switch();
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w38, ya[t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vb, yb[t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, yc[t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vb, ya[t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, yb[t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, ya[t], acc[t], 0, 0, 0);
+            }
+            x3_mfma_switch();
+        } else {
+        bf16x8 wc[2], wn[2], x0[NT], x1[NT], x2[NT];
+        s16x4 w8[2], y0[NT], y1[NT], y2[NT];
+#pragma unroll
+        for (int q = 0; q < 2; q++) wc[q] = *(const bf16x8 *)(wp + ((0 * 2 + q) * 64 + lane) * 16);
 #pragma unroll
         for (int t = 0; t < NT; t++) x0[t] = *(const bf16x8 *)(X + xoff(0, t));
 #pragma unroll
@@ -241,7 +301,9 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             for (int t = 0; t < NT; t++) x1[t] = *(const bf16x8 *)(X + xoff(s, t) + 32);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 2; q >= 0; q--)
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3c[s], x0[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int q = 1; q >= 0; q--)
 #pragma unroll
                 for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[q], x0[t], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -249,12 +311,12 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             for (int t = 0; t < NT; t++) x2[t] = *(const bf16x8 *)(X + xoff(s, t) + 64);
             if (s + 1 < 4) {
 #pragma unroll
-                for (int q = 0; q < 3; q++) wn[q] = *(const bf16x8 *)(wp + (((s + 1) * 3 + q) * 64 + lane) * 16);
+                for (int q = 0; q < 2; q++) wn[q] = *(const bf16x8 *)(wp + (((s + 1) * 2 + q) * 64 + lane) * 16);
 #pragma unroll
                 for (int t = 0; t < NT; t++) x0[t] = *(const bf16x8 *)(X + xoff(s + 1, t));
             } else {
 #pragma unroll
-                for (int q = 0; q < 3; q++) w8[q] = *(const s16x4 *)(wp + 4 * 3 * 64 * 16 + (q * 64 + lane) * 8);
+                for (int q = 0; q < 2; q++) w8[q] = *(const s16x4 *)(wp + 4 * 2 * 64 * 16 + (q * 64 + lane) * 8);
 #pragma unroll
                 for (int t = 0; t < NT; t++) y0[t] = *(const s16x4 *)(X + aC[t] + T8);
             }
@@ -268,7 +330,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < 4) {
 #pragma unroll
-                for (int q = 0; q < 3; q++) wc[q] = wn[q];
+                for (int q = 0; q < 2; q++) wc[q] = wn[q];
             }
         }
 #pragma unroll
@@ -276,9 +338,18 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             y1[t] = *(const s16x4 *)(X + aC[t] + T8 + 32);
             y2[t] = *(const s16x4 *)(X + aC[t] + T8 + 64);
         }
+        const s16x4 w38 = w3c8;
+        if (l + 1 < L) { // the next layer's third weight plane sets out now (its slices' registers were read for the last time above)
+            const unsigned char *g3 = x3.wt3 + (size_t)(l + 1) * XG::LAYER3_B;
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) w3c[sl] = *(const bf16x8 *)(g3 + (sl * 64 + lane) * 16);
+            w3c8 = *(const s16x4 *)(g3 + 4 * 64 * 16 + lane * 8);
+        }
         x3_mfma_switch();
 #pragma unroll
-        for (int q = 2; q >= 0; q--)
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w38, y0[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int q = 1; q >= 0; q--)
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w8[q], y0[t], acc[t], 0, 0, 0);
 #pragma unroll
@@ -288,6 +359,9 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w8[0], y2[t], acc[t], 0, 0, 0);
         x3_mfma_switch();
+        }
+        // (the batch-norm constants are read here, not at the top of the layer: 8 registers less through the slices)
+        const f32x4 scale = *(const f32x4 *)(ep + 16 + 4 * g), shift = *(const f32x4 *)(ep + 32 + 4 * g);
         wave_lds_handover(); // every lane's reads of X are done (their results feed the MFMAs above) before X is rewritten
 #pragma unroll
         for (int t = 0; t < NT; t++) {

@@ -174,6 +174,12 @@ int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, double *ms_per
  * whole launch -- tree step, network and move in the same wave.  (2 and 4 were launch structures that measured slower
  * and were retired: tools/experimental/.) */
 int bb_selfplay_mode(bb_engine *e);
+/* Which arithmetic the loaded network's conv tower runs in (after bb_load_weights): 0 float32 MFMA, fused 16-filter
+ * tower (bit-identical to the k-ordered fmaf chain); 1 float32 MFMA, one launch per conv layer (any multiple of 16
+ * filters); 2 float32 results on the bf16 matrix pipe -- every operand split exactly into three bf16 values, six MFMA
+ * products per K slice, float32 accumulation (16-filter networks of Connect4 / TicTacToe; 1e-5 of form 0, not
+ * bit-identical; the environment variable BB_NET_X3=0 selects form 0 instead).  Negative: BB_ERR_*. */
+int bb_net_form(bb_engine *e);
 
 /* Network.getEvaluation + getPolicy for n positions (Network.py:48-64; graph NetworkFactory.py:22-183).
  * Exactly one of states (packed) / planes (int8 [n][H][W][C], what AsInputArray returns) is non-NULL.
