@@ -675,12 +675,22 @@ static void bf16_split3(float v, uint16_t out[3]) {
 // wt3:  per layer [slice][lane][8] then [lane][4]: the third plane alone
 static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vector<uint16_t> &wt12, std::vector<uint16_t> &wt3) {
     const int F = 16, C = w->C, R = w->R;
-    w0.assign((3 * 64 * 8 + 3 * 64 * 4), 0);
+    const bool wide = C > 4; // DragonChess: one K = 32 slice per tap, lane group g = input planes 8g .. 8g + 7
+    w0.assign(wide ? (size_t)9 * 3 * 64 * 8 : (size_t)(3 * 64 * 8 + 3 * 64 * 4), 0);
     const size_t per12 = 4 * 2 * 64 * 8 + 2 * 64 * 4, per3 = 4 * 64 * 8 + 64 * 4;
     wt12.assign((size_t)2 * R * per12, 0);
     wt3.assign((size_t)2 * R * per3, 0);
     uint16_t h[3];
-    for (int lane = 0; lane < 64; lane++) {
+    for (int lane = 0; wide && lane < 64; lane++) {
+        const int f = lane & 15, g = lane >> 4;
+        for (int tap = 0; tap < 9; tap++)
+            for (int i = 0; i < 8; i++) {
+                int ch = 8 * g + i;
+                bf16_split3(ch < C ? w->conv0_k[((size_t)tap * C + ch) * F + f] : 0.f, h);
+                for (int q = 0; q < 3; q++) w0[(((size_t)tap * 3 + q) * 64 + lane) * 8 + i] = h[q];
+            }
+    }
+    for (int lane = 0; !wide && lane < 64; lane++) {
         const int f = lane & 15, g = lane >> 4;
         for (int i = 0; i < 8; i++) {
             int tap = 2 * g + (i >> 2), ch = i & 3;
@@ -791,7 +801,7 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     HIPCHK(hipMemcpy(d_head, head.data(), head.size() * 4, hipMemcpyHostToDevice));
     // the bf16-pipe form of the same network (dense games, 16 filters); BB_NET_X3=0 keeps the float32 MFMA path
     {
-        const bool want = F == 16 && C <= 4 && !e->general_net && !(getenv("BB_NET_X3") && atoi(getenv("BB_NET_X3")) == 0);
+        const bool want = F == 16 && C <= 32 && !e->general_net && !(getenv("BB_NET_X3") && atoi(getenv("BB_NET_X3")) == 0);
         if (want) {
             std::vector<uint16_t> xw0, xw12, xw3;
             pack_x3(w, xw0, xw12, xw3);
@@ -845,7 +855,7 @@ static int launch_net(bb_engine *e, int n, const typename G::State *states, cons
     // positions per wave: the fewest that still put a wave on every SIMD (1024 waves) -- a single FindMove position
     // must not pay for the 11 MFMA tiles of a 4-position wave
     constexpr int PW = NetPW<G>::v;
-    if constexpr (G::C <= 4) {
+    {
         if (e->x3.w0) { // one position per wave on the bf16 pipe: the same arithmetic everywhere (bb_net_eval, search, self-play)
             k_net_x3<G><<<(n + 3) / 4, 256, 0, st>>>(e->net, e->x3, n, nullptr, nullptr, states, planes, game_id, serial, noise, value,
                                                      logits, policy, pstride);
@@ -1329,7 +1339,7 @@ extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
                     bool timed = e->time_every > 0 && e->ev_used + 2 <= e->ev_pool.size();
                     if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
                     k_set_i32<<<1, 1, 0, e->stream>>>(e->dev.visit_pool, e->dev.n_slots * now * e->sims_now);
-                    k_dc_selfplay_fused<<<nblk((size_t)e->dev.n_slots * 64), 256, 0, e->stream>>>(e->dev, e->edges, e->net, e->cfg.noise_on);
+                    k_dc_selfplay_fused<<<nblk((size_t)e->dev.n_slots * 64), 256, 0, e->stream>>>(e->dev, e->edges, e->net, e->x3, e->cfg.noise_on);
                     HIPCHK(hipGetLastError());
                     if (timed) {
                         HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));

@@ -195,6 +195,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
         wg_refill = 0;
     }
     if (threadIdx.x < GW) gstate[threadIdx.x] = 0;
+#ifdef BB_STAMPS_NET
+    if (threadIdx.x < 8) s_net_stamps[threadIdx.x] = 0;
+#endif
     if (threadIdx.x < MEGA2_QCAP) qc.q[threadIdx.x] = -1;
     for (int i = threadIdx.x; i < NETW * WAVE_F; i += MEGA2_THREADS) lds[i] = 0.f;
     NetDev ndl = nd;
@@ -365,7 +368,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
                 if (l64 == 0) d.sims_left[li] -= 1;
             }
 #ifdef BB_STAMPS_NET
-            if (l64 == 0) atomicAdd(&g_net_stamps[5], (unsigned long long)(clock64() - _na));
+            if (l64 == 0) atomicAdd(&s_net_stamps[5], (unsigned long long)(clock64() - _na));
 #endif
             }
             release_global_then_lds(); // value / policy (and the tree rows) before the state word
@@ -388,6 +391,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
 #endif
     }
     __syncthreads();
+#ifdef BB_STAMPS_NET
+    if (threadIdx.x < 8) atomicAdd(&g_net_stamps[threadIdx.x], s_net_stamps[threadIdx.x]);
+#endif
     if (qc.abort_flag) { // a wait ran into the wall-clock limit: surfaces as bb_counters.overflow
         if (threadIdx.x == 0) d.ctr[6] += 1;
         // a leaf that was queued but never evaluated must not be applied by the next launch (its mailbox holds the

@@ -9,6 +9,7 @@
 // results are identical (tests/test_gpu_mcts.py compares both with the oracle).
 #pragma once
 #include "net.hip.h"
+#include "net_x3.hip.h"
 #include "tree_dc.hip.h"
 
 #define DC_HEAD_FLOATS 12288 // packed head parameters (2 x 4032 policy kernel + 4032 bias + the small ones) kept in LDS: 48 KB
@@ -48,6 +49,20 @@ __device__ __attribute__((noinline)) void dc_fused_apply(const TreeDev &d_, cons
     tl = as_lds(tl);
     hl = as_lds(hl);
     dc_phase_apply(d, E, g, lane, tl, hl);
+    __threadfence_block();
+}
+// The same on the bf16 matrix pipe (net_x3.hip.h): every operand plane of the tower streams from L2 a layer ahead (this
+// kernel's LDS holds the four waves' scratch and the 4032-wide head).
+__device__ __attribute__((noinline)) void dc_fused_net_x3(const NetDev &nd_, const NetX3 &x3_, const TreeDev &d_, const int *slot, float *nl,
+                                                          DCHeadLocal *hl) {
+    const NetDev &nd = *as_lds(&nd_);
+    const NetX3 &x3 = *as_lds(&x3_);
+    const TreeDev &d = *as_lds(&d_);
+    slot = as_lds(slot);
+    nl = as_lds(nl);
+    hl = as_lds(hl);
+    net_body_x3<DragonChess, false>(nd, x3, 1, 0, slot, (unsigned char *)nl, (const DCState *)d.leaf_state, nullptr, d.leaf_game_id,
+                                    d.leaf_serial, 0, nullptr, nullptr, nullptr, DragonChess::A, true, &hl->h);
     __threadfence_block();
 }
 __device__ __attribute__((noinline)) void dc_fused_move(const TreeDev &d_, const DCEdges &E_, int g, int lane, float *tl, const DCHeadLocal *hl) {
@@ -104,10 +119,11 @@ struct DCShadow {
 
 #define DC_SIM_CHUNK 20 // simulations a wave draws from the launch's pool at a time (~1 ms of work)
 
-__global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdges E_arg, NetDev nd_arg, int noise_on) {
+__global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdges E_arg, NetDev nd_arg, NetX3 x3_arg, int noise_on) {
     using NG = NetGeom<DragonChess, 1>;
     // the tree's scratch (the 4032-float policy image) and the network's activations are never live together
-    constexpr int TREE_BYTES = DC_LDS_FLOATS * 4, NET_BYTES = NG::WAVE_FLOATS * 4;
+    constexpr int TREE_BYTES = DC_LDS_FLOATS * 4;
+    constexpr int NET_BYTES = NG::WAVE_FLOATS * 4 > X3Geom<DragonChess>::WAVE_BYTES ? NG::WAVE_FLOATS * 4 : X3Geom<DragonChess>::WAVE_BYTES;
     constexpr int WAVE_BYTES = ((TREE_BYTES > NET_BYTES ? TREE_BYTES : NET_BYTES) + 15) / 16 * 16;
     static_assert(4 * WAVE_BYTES + DC_HEAD_FLOATS * 4 + 1024 <= 163840, "four waves' scratch and the head weights must fit the 160 KiB LDS");
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[4][WAVE_BYTES];
@@ -119,6 +135,7 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
     __shared__ TreeDev s_d;
     __shared__ DCEdges s_E;
     __shared__ NetDev s_nd;
+    __shared__ NetX3 s_x3;
     __shared__ DCShadow shadow;
     const int g0 = blockIdx.x * 4;
     const int n_mine = d_arg.n_slots - g0 < 4 ? d_arg.n_slots - g0 : 4;
@@ -132,6 +149,7 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
         s_E = El;
         s_nd = nd_arg;
         s_nd.head = s_head;
+        s_x3 = x3_arg;
     }
     if (threadIdx.x < 4) {
         using LP = const __attribute__((address_space(3))) float *;
@@ -187,8 +205,10 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
 #ifdef BB_STAMPS
         long long c1 = clock64();
 #endif
-        if (d.pend_leaf[g] >= 0) // (uniform) a leaf was posted: evaluate it right here
-            dc_fused_net(nd, d, &myslot[wv], nl, hl);
+        if (d.pend_leaf[g] >= 0) { // (uniform) a leaf was posted: evaluate it right here
+            if (s_x3.w0) dc_fused_net_x3(nd, s_x3, d, &myslot[wv], nl, hl);
+            else dc_fused_net(nd, d, &myslot[wv], nl, hl);
+        }
 #ifdef BB_STAMPS
         DST(0, c1 - c0);          // tree phases (tools/dc_stamps.py)
         DST(2, clock64() - c1);   // network

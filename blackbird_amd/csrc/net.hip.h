@@ -54,8 +54,9 @@ struct NetDev {
 __device__ unsigned long long g_net_stamps[8];
 #endif
 #ifdef BB_STAMPS_NET
-#define NSTAMP_ON 1 // diagnostic build: cycles per section of net_body, summed over calls
-#define NSTAMP(i) do { long long _t = clock64(); if (lane == 0) atomicAdd(&g_net_stamps[i], (unsigned long long)(_t - _ns)); _ns = clock64(); } while (0)
+#define NSTAMP_ON 1 // diagnostic build: cycles per section of net_body, summed over calls (per workgroup in LDS, flushed by the persistent kernel)
+__shared__ unsigned long long s_net_stamps[8];
+#define NSTAMP(i) do { long long _t = clock64(); if (lane == 0) atomicAdd(&s_net_stamps[i], (unsigned long long)(_t - _ns)); _ns = clock64(); } while (0)
 #else
 #define NSTAMP(i) do {} while (0)
 #endif

@@ -17,7 +17,7 @@
 // search is compared on the evaluations the engine itself produced (bb_net_eval_keyed, tests/test_gpu_noise_parity.py).
 //
 // Layout (one wave = one position, its activations never leave LDS):
-//   X    [slot][plane 0..2][16 ch] bf16 = 96 B per pixel slot (zero halo as in net.hip.h); the three planes of a pixel's 8
+//   X    [slot][plane 0..2][16 ch] bf16 (+ 16 B pad: 112 B per pixel slot, bank-conflict-free; zero halo as in net.hip.h); the three planes of a pixel's 8
 //        channels are one ds_read_b128 each; written in place (a layer's reads are complete before its epilogue starts,
 //        the block input for the skip connection stays in registers)
 //   inp  [slot][4 ch] bf16: the input planes (small integers: exact in bf16, no split)
@@ -36,13 +36,16 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <class G>
 struct X3Geom {
     static constexpr int H = G::H, W = G::W, CIN = G::C, A = G::A, HW = H * W;
-    static_assert(CIN <= 4, "the first conv packs 4 input planes per tap");
+    static_assert(CIN <= 32, "the first conv packs at most 32 input planes per tap");
     static_assert(HW <= 64, "one lane per pixel in the heads");
+    static constexpr bool WIDE_IN = CIN > 4;                        // DragonChess (17 planes): one K = 32 slice per tap
     static constexpr int SLOTS = (H + 2) * (W + 1) + 1;
     static constexpr int NT = (HW + 15) / 16;
-    static constexpr int SLOT_B = 96;                              // bytes of X per slot
+    // bytes of X per slot: 3 planes x 32 B + 16 B of padding -- at 96 B the 16 pixels of a tile start 24 banks apart (period
+    // 8: every ds_read_b128 of a pixel plane is a 2-way bank conflict), at 112 B they start 28 banks apart (period 16: none)
+    static constexpr int SLOT_B = 112;
     static constexpr int X_B = SLOTS * SLOT_B;
-    static constexpr int INP_B = (SLOTS * 8 + 15) / 16 * 16;
+    static constexpr int INP_B = WIDE_IN ? 0 : (SLOTS * 8 + 15) / 16 * 16; // wide inputs ([32 ch] bf16 = 64 B) sit in their X slot
     static constexpr int STATE_B = ((int)sizeof(typename G::State) + 15) / 16 * 16;
     static constexpr int WAVE_BYTES = X_B + INP_B + STATE_B;
     // packed weights (bytes).  A tower layer's first two planes (4 slices x 2 planes x 64 lanes x 16 B + tap 8: 2 planes x 64
@@ -50,7 +53,8 @@ struct X3Geom {
     // array that every kernel streams from L2, a layer ahead -- with all three planes in LDS only 5 network waves fit a CU.
     static constexpr int LAYER12_B = 4 * 2 * 64 * 16 + 2 * 64 * 8; // 9 216
     static constexpr int LAYER3_B = 4 * 64 * 16 + 64 * 8;          // 4 608
-    static constexpr int W0_B = 3 * 64 * 16 + 3 * 64 * 8;          // first conv: taps 0..7 (K = 32) + tap 8 (K = 16), 3 planes
+    // first conv, 3 planes: narrow input -- taps 0..7 (K = 32) + tap 8 (K = 16); wide input -- 9 taps x (K = 32: 32 planes)
+    static constexpr int W0_B = WIDE_IN ? 9 * 3 * 64 * 16 : 3 * 64 * 16 + 3 * 64 * 8;
 };
 
 struct NetX3 {             // device pointers of the packed operands (nullptr: this network has no x3 form)
@@ -100,9 +104,11 @@ template <class G, bool WLDS, bool LEAN = false>
 __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, int n, int pos0, const int *slot_list,
                                             unsigned char *wl, const typename G::State *states, const int8_t *planes,
                                             const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
-                                            float *logits_out, float *policy_out, int pstride, bool zero_lds) {
+                                            float *logits_out, float *policy_out, int pstride, bool zero_lds,
+                                            WideHead *compact = nullptr) {
     using XG = X3Geom<G>;
     constexpr int W = XG::W, CIN = XG::CIN, HW = XG::HW, NT = XG::NT, SB = XG::SLOT_B;
+    constexpr bool WIDE_IN = XG::WIDE_IN;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, nn = lane & 15, gh = g >> 1, gl = g & 1;
     unsigned char *X = wl;
@@ -121,12 +127,17 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     // ---- prologue: the board, the first conv's operands, zero fill -------------------------------------------------
     const typename G::State my_state = planes ? G::initial() : states[OI(live ? pos0 : 0)];
     const unsigned char *w0p = x3.w0;
-    bf16x8 w0a[3];
+    bf16x8 w0a[WIDE_IN ? 27 : 3]; // wide input: [tap][plane], all requested now (L2), consumed tap by tap
     s16x4 w0b[3];
+    if constexpr (WIDE_IN) {
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-        w0a[q] = *(const bf16x8 *)(w0p + (q * 64 + lane) * 16);
-        w0b[q] = *(const s16x4 *)(w0p + 3 * 64 * 16 + (q * 64 + lane) * 8);
+        for (int i = 0; i < 27; i++) w0a[i] = *(const bf16x8 *)(w0p + (i * 64 + lane) * 16);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            w0a[q] = *(const bf16x8 *)(w0p + (q * 64 + lane) * 16);
+            w0b[q] = *(const s16x4 *)(w0p + 3 * 64 * 16 + (q * 64 + lane) * 8);
+        }
     }
     const f32x4 bias0 = *(const f32x4 *)(nd.epi + 4 * g), scale0 = *(const f32x4 *)(nd.epi + 16 + 4 * g),
                 shift0 = *(const f32x4 *)(nd.epi + 32 + 4 * g);
@@ -137,6 +148,27 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     wave_lds_handover();
     if (!planes && lane == 0) *sst = my_state;
     wave_lds_handover();
+    if constexpr (WIDE_IN) {
+        if (lane < HW && live) { // input planes of pixel `lane`: 32 x bf16 in the first 64 B of its X slot
+            const int y = lane / W, x = lane % W;
+            int8_t v[CIN];
+            if (planes) {
+                const int8_t *src = planes + ((size_t)pos0 * HW + lane) * CIN;
+#pragma unroll
+                for (int c = 0; c < CIN; c++) v[c] = src[c];
+            } else {
+                G::encode_cell(*sst, y, x, v);
+            }
+            unsigned b[32];
+#pragma unroll
+            for (int c = 0; c < 32; c++) b[c] = c < CIN ? __float_as_uint((float)v[c]) >> 16 : 0u;
+            unsigned char *dst = X + ((y + 1) * (W + 1) + (x + 1)) * SB;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                *(u32x4 *)(dst + 16 * k) = u32x4{b[8 * k] | (b[8 * k + 1] << 16), b[8 * k + 2] | (b[8 * k + 3] << 16),
+                                                 b[8 * k + 4] | (b[8 * k + 5] << 16), b[8 * k + 6] | (b[8 * k + 7] << 16)};
+        }
+    } else
     if (lane < HW && live) { // input planes of pixel `lane`: 4 x bf16 (the int8 plane values are exact in bf16)
         const int y = lane / W, x = lane % W;
         int8_t v[4] = {0, 0, 0, 0};
@@ -180,6 +212,19 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     {
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = bias0;
+        if constexpr (WIDE_IN) { // one K = 32 slice per tap: lane group g holds input planes 8g .. 8g + 7 of the tap's pixel
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                bf16x8 b[NT];
+#pragma unroll
+                for (int t = 0; t < NT; t++) b[t] = *(const bf16x8 *)(X + aC[t] + g * 8 + tapoff(tap) * SB); // (aC = base SB + 8 g)
+#pragma unroll
+                for (int q = 2; q >= 0; q--)
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[tap * 3 + q], b[t], acc[t], 0, 0, 0);
+            }
+            wave_lds_handover(); // the inputs are read (their values feed the MFMAs above) before the output planes overwrite them
+        } else {
         bf16x8 b[NT];
         s16x4 b8[NT];
 #pragma unroll
@@ -199,6 +244,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0b[q], b8[t], acc[t], 0, 0, 0);
         x3_mfma_switch();
+        }
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             f32x4 y;
@@ -221,14 +267,27 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     // ---- residual tower ------------------------------------------------------------------------------------------------
     const int R_eff = (nd.dbg & 2) ? 0 : nd.R;
     const int L = 2 * R_eff;
-    // plane 3 of the tower weights comes from L2: the five operands of a layer are requested a layer ahead
-    bf16x8 w3c[4];
-    s16x4 w3c8;
-    if (L > 0) {
+    // plane 3 of the tower weights comes from L2: the five operands of a layer are requested a layer ahead.  So are planes 1
+    // and 2 when the caller does not keep them in LDS (!WLDS: batch kernels and the DragonChess wave-per-game kernel, whose
+    // LDS holds the 4032-wide head): 54 registers of weights in flight, which a 256-thread workgroup can afford.
+    bf16x8 w3c[4], w12c[WLDS ? 1 : 4][2];
+    s16x4 w3c8, w12c8[2];
+    auto request_layer = [&](int l) __attribute__((always_inline)) {
+        const unsigned char *g3 = x3.wt3 + (size_t)l * XG::LAYER3_B;
 #pragma unroll
-        for (int sl = 0; sl < 4; sl++) w3c[sl] = *(const bf16x8 *)(x3.wt3 + (sl * 64 + lane) * 16);
-        w3c8 = *(const s16x4 *)(x3.wt3 + 4 * 64 * 16 + lane * 8);
-    }
+        for (int sl = 0; sl < 4; sl++) w3c[sl] = *(const bf16x8 *)(g3 + (sl * 64 + lane) * 16);
+        w3c8 = *(const s16x4 *)(g3 + 4 * 64 * 16 + lane * 8);
+        if constexpr (!WLDS) {
+            const unsigned char *g12 = x3.wt12 + (size_t)l * XG::LAYER12_B;
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) w12c[sl][q] = *(const bf16x8 *)(g12 + ((sl * 2 + q) * 64 + lane) * 16);
+#pragma unroll
+            for (int q = 0; q < 2; q++) w12c8[q] = *(const s16x4 *)(g12 + 4 * 2 * 64 * 16 + (q * 64 + lane) * 8);
+        }
+    };
+    if (L > 0) request_layer(0);
     auto conv_layer = [&](const int l, auto skip_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr bool SKIP = decltype(skip_tag)::value, LAST = decltype(last_tag)::value;
         const float *ep = nd.epi + (size_t)(1 + l) * 48;
@@ -246,6 +305,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
         auto xoff = [&](int s, int t) __attribute__((always_inline)) { return s < 3 ? aA[t] + s * (W + 1) * SB : aB[t] + 2 * SB; };
         constexpr int T8 = (2 * (W + 1) + 2) * SB;
         if constexpr (LEAN) {
+            static_assert(!LEAN || WLDS, "the in-place schedule reads its weights from LDS");
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const bf16x8 wa = *(const bf16x8 *)(wp + ((s * 2 + 0) * 64 + lane) * 16), wb = *(const bf16x8 *)(wp + ((s * 2 + 1) * 64 + lane) * 16);
@@ -271,12 +331,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
                 yc[t] = *(const s16x4 *)(X + aC[t] + T8 + 64);
             }
             const s16x4 w38 = w3c8;
-            if (l + 1 < L) {
-                const unsigned char *g3 = x3.wt3 + (size_t)(l + 1) * XG::LAYER3_B;
-#pragma unroll
-                for (int sl = 0; sl < 4; sl++) w3c[sl] = *(const bf16x8 *)(g3 + (sl * 64 + lane) * 16);
-                w3c8 = *(const s16x4 *)(g3 + 4 * 64 * 16 + lane * 8);
-            }
+            if (l + 1 < L) request_layer(l + 1);
             x3_mfma_switch();
 #pragma unroll
             for (int t = 0; t < NT; t++) {
@@ -292,7 +347,10 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
         bf16x8 wc[2], wn[2], x0[NT], x1[NT], x2[NT];
         s16x4 w8[2], y0[NT], y1[NT], y2[NT];
 #pragma unroll
-        for (int q = 0; q < 2; q++) wc[q] = *(const bf16x8 *)(wp + ((0 * 2 + q) * 64 + lane) * 16);
+        for (int q = 0; q < 2; q++) {
+            if constexpr (WLDS) wc[q] = *(const bf16x8 *)(wp + ((0 * 2 + q) * 64 + lane) * 16);
+            else wc[q] = w12c[0][q];
+        }
 #pragma unroll
         for (int t = 0; t < NT; t++) x0[t] = *(const bf16x8 *)(X + xoff(0, t));
 #pragma unroll
@@ -311,12 +369,18 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             for (int t = 0; t < NT; t++) x2[t] = *(const bf16x8 *)(X + xoff(s, t) + 64);
             if (s + 1 < 4) {
 #pragma unroll
-                for (int q = 0; q < 2; q++) wn[q] = *(const bf16x8 *)(wp + (((s + 1) * 2 + q) * 64 + lane) * 16);
+                for (int q = 0; q < 2; q++) {
+                    if constexpr (WLDS) wn[q] = *(const bf16x8 *)(wp + (((s + 1) * 2 + q) * 64 + lane) * 16);
+                    else wn[q] = w12c[WLDS ? 0 : s + 1][q];
+                }
 #pragma unroll
                 for (int t = 0; t < NT; t++) x0[t] = *(const bf16x8 *)(X + xoff(s + 1, t));
             } else {
 #pragma unroll
-                for (int q = 0; q < 2; q++) w8[q] = *(const s16x4 *)(wp + 4 * 2 * 64 * 16 + (q * 64 + lane) * 8);
+                for (int q = 0; q < 2; q++) {
+                    if constexpr (WLDS) w8[q] = *(const s16x4 *)(wp + 4 * 2 * 64 * 16 + (q * 64 + lane) * 8);
+                    else w8[q] = w12c8[q];
+                }
 #pragma unroll
                 for (int t = 0; t < NT; t++) y0[t] = *(const s16x4 *)(X + aC[t] + T8);
             }
@@ -339,12 +403,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             y2[t] = *(const s16x4 *)(X + aC[t] + T8 + 64);
         }
         const s16x4 w38 = w3c8;
-        if (l + 1 < L) { // the next layer's third weight plane sets out now (its slices' registers were read for the last time above)
-            const unsigned char *g3 = x3.wt3 + (size_t)(l + 1) * XG::LAYER3_B;
-#pragma unroll
-            for (int sl = 0; sl < 4; sl++) w3c[sl] = *(const bf16x8 *)(g3 + (sl * 64 + lane) * 16);
-            w3c8 = *(const s16x4 *)(g3 + 4 * 64 * 16 + lane * 8);
-        }
+        if (l + 1 < L) request_layer(l + 1); // (this layer's slice registers were read for the last time above; w8 / w38 are copies)
         x3_mfma_switch();
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w38, y0[t], acc[t], 0, 0, 0);
@@ -429,7 +488,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     }
     NSTAMP(3);
     head_one<G>(nd, pooled_sum(x), pooled_sum(x0), pooled_sum(x1), live ? OI(pos0) : 0, live, game_id, serial, noise, value_out,
-                logits_out, policy_out, pstride, nullptr);
+                logits_out, policy_out, pstride, compact);
     NSTAMP(4);
 }
 

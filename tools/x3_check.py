@@ -28,3 +28,23 @@ for game in (_lib.GAME_CONNECT4, _lib.GAME_TICTACTOE):
             print(f"game {game} perturb {perturb} R {R}: value {np.abs(v1-ov).max():.2e} logits abs {np.abs(l1-ol).max():.2e} "
                   f"rel {(np.abs(l1-ol)/np.maximum(1,np.abs(ol))).max():.2e} policy {np.abs(p1-op).max():.2e} | logit scale {np.abs(ol).max():.2f} | states==planes {same}")
             eng.close()
+# DragonChess (17 input planes, 4032-wide head)
+game = _lib.GAME_DRAGONCHESS
+for R in (4, 1):
+    w = W.init_weights(17, 16, R, 16, 4032, seed=13, perturb=True)
+    flat = W.flatten(w)
+    eng = _lib.Engine(game, n_slots=2, sims_per_move=2, evaluator=_lib.EVAL_NET, max_plies=8)
+    eng.load_weights(flat)
+    rng = np.random.RandomState(5)
+    n = 11
+    boards = np.zeros((n, 8, 8), dtype=np.int8)
+    for i in range(n):
+        m = rng.rand(8, 8) < 0.35
+        boards[i][m] = rng.choice([-6, -5, -4, -3, -2, -1, 1, 2], m.sum())
+    st = _lib.pack_dc(boards, rng.randint(1, 3, n), rng.randint(0, 3, n), rng.randint(0, 2, (n, 4)))
+    planes = _lib.game_encode(game, st)
+    v1, l1, p1 = eng.net_eval(states=st)
+    v2, l2, p2 = eng.net_eval(planes=planes)
+    ov, ol, op = orc.net_forward(orc.NetWeights(8, 8, 17, 16, R, 16, 4032, flat), planes)
+    print(f"DragonChess R {R} form {eng.net_form()}: value {np.abs(v1-ov).max():.2e} logits rel {(np.abs(l1-ol)/np.maximum(1,np.abs(ol))).max():.2e} policy {np.abs(p1-op).max():.2e} | states==planes {np.array_equal(l1,l2) and np.array_equal(v1,v2)}")
+    eng.close()
