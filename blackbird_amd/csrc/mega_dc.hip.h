@@ -157,6 +157,9 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
         s_hl[threadIdx.x].pdb = (LP)s_head + nd_arg.off_pdb;
         s_hl[threadIdx.x].h = WideHead{0.f, 0.f, 0.f, 0.f, 0.f};
     }
+#ifdef BB_STAMPS_NET
+    if (threadIdx.x < 8) s_net_stamps[threadIdx.x] = 0;
+#endif
     __syncthreads();
     (void)noise_on; // E.noise_on carries it to the expansion
     const TreeDev &d = s_d;
@@ -220,5 +223,8 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
         for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[(size_t)((g0 + g) & 63) * 16 + i], ((unsigned long long *)(lds + DC_STAMP_OFF))[i]);
 #endif
     __syncthreads();
+#ifdef BB_STAMPS_NET
+    if (threadIdx.x < 8) atomicAdd(&g_net_stamps[threadIdx.x], s_net_stamps[threadIdx.x]);
+#endif
     shadow.store(d_arg, E_arg, g0, n_mine, blockDim.x); // hand the per-game state back to HBM
 }

@@ -9,6 +9,8 @@ p["clock_GHz"] = clk / 1e9
 p["MfmaUtil_pct"] = 100.0 * p["SQ_VALU_MFMA_BUSY_CYCLES"] / (p["GRBM_GUI_ACTIVE"] / 8 * 1024)  # 1024 SIMDs
 d_mf = next(v for k, v in p.items() if k.startswith("dur_ms_SQ_ACTIVE_INST_LDS"))
 p["mfma_flops_TF_issued"] = p["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / (d_mf * 1e-3) / 1e12
+if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in p:  # (the bf16-pipe network: every float32 product is six of these)
+    p["mfma_bf16_flops_TF_issued"] = p["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512 / (d_mf * 1e-3) / 1e12
 if p.get("SQ_LDS_IDX_ACTIVE"):
     p["lds_conflict_frac"] = p["SQ_LDS_BANK_CONFLICT"] / p["SQ_LDS_IDX_ACTIVE"]
 p["wave_cycles_parked_frac"] = p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"]

@@ -15,7 +15,7 @@ echo "dc stats done"
 cd $REPO
 bash tools/pmc_collect.sh gpurun_out/${TAG}_pmc_c2 --steps 4 --warmup 2 --prefill 16 --no-cpu-baseline
 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_c2 k_selfplay_queue gpurun_out/${TAG}_pmc_c2/summary.json > /dev/null
-python3 tools/pmc_derive.py gpurun_out/${TAG}_pmc_c2/summary.json gpurun_out/${TAG}_queue_pmc_summary.json "kernel=k_selfplay_queue<Connect4,8>" "command=bench.py --steps 4 --warmup 2 --prefill 16 --no-cpu-baseline (timed-region dispatch)" > /dev/null
+python3 tools/pmc_derive.py gpurun_out/${TAG}_pmc_c2/summary.json gpurun_out/${TAG}_queue_pmc_summary.json "kernel=k_selfplay_queue<Connect4,8,x3,12>" "command=bench.py --steps 4 --warmup 2 --prefill 16 --no-cpu-baseline (timed-region dispatch)" > /dev/null
 bash tools/pmc_collect.sh gpurun_out/${TAG}_pmc_dc --workload dc --steps 4 --warmup 1 --prefill 16 --no-cpu-baseline
 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_dc k_dc_selfplay_fused gpurun_out/${TAG}_pmc_dc/summary.json > /dev/null
 python3 tools/pmc_derive.py gpurun_out/${TAG}_pmc_dc/summary.json gpurun_out/${TAG}_dc_pmc_summary.json "kernel=k_dc_selfplay_fused" "command=bench.py --workload dc --steps 4 --warmup 1 --prefill 16 --no-cpu-baseline (timed-region dispatch)" > /dev/null
