@@ -40,7 +40,11 @@ struct X3Geom {
     static_assert(HW <= 64, "one lane per pixel in the heads");
     static constexpr bool WIDE_IN = CIN > 4;                        // DragonChess (17 planes): one K = 32 slice per tap
     static constexpr int SLOTS = (H + 2) * (W + 1) + 1;
-    static constexpr int NT = (HW + 15) / 16;
+    // pixels per 16-column MFMA tile: whole board rows (Connect4: 2 rows = 14 pixels, the last two columns repeat the 14th).
+    // Slots of two adjacent rows are distinct modulo 16, so the 16 lanes of an operand read hit 16 different bank groups;
+    // 16 consecutive pixels span three rows and two of them collide.
+    static constexpr int PPT = (W < 16 && HW > 16) ? (16 / W) * W : (HW < 16 ? HW : 16);
+    static constexpr int NT = (HW + PPT - 1) / PPT;
     // bytes of X per slot: 3 planes x 32 B + 16 B of padding -- at 96 B the 16 pixels of a tile start 24 banks apart (period
     // 8: every ds_read_b128 of a pixel plane is a 2-way bank conflict), at 112 B they start 28 banks apart (period 16: none)
     static constexpr int SLOT_B = 112;
@@ -195,7 +199,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     const int t0off = tapoff(2 * g) * 8, t1off = tapoff(2 * g + 1) * 8; // first conv: lane group g holds taps 2g, 2g + 1
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        int q = t * 16 + nn;
+        int q = t * XG::PPT + (nn < XG::PPT ? nn : XG::PPT - 1);
         int qq = q < HW ? q : HW - 1;
         int y = qq / W, x = qq % W;
         int base = ((y + 1) * (W + 1) + (x + 1) - TAP0);
