@@ -7,6 +7,7 @@
 #include "net.hip.h"
 #include "net_x3.hip.h"
 #include "gnet.hip.h"
+#include "gnet_x3.hip.h"
 #include "tree.hip.h"
 #include "tree_dc.hip.h"
 #include "mega2.hip.h"
@@ -193,6 +194,8 @@ struct bb_engine {
     int net_F = 0, net_C = 0;
     bool general_net = false; // F != 16 (or BB_GNET=1): one implicit-GEMM launch per conv layer (gnet.hip.h)
     GNetDev gnet = {};
+    GNetX3 gx3 = {nullptr, {nullptr, nullptr}}; // tower layers of the general-filter network on the bf16 matrix pipe (gnet_x3.hip.h)
+    size_t gx3_bytes = 0;
     int gnet_C = 0;
     size_t net_sizes[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr;
@@ -535,6 +538,26 @@ static void bn_fold(const float *bn, int F, float *scale, float *shift) {
 
 
 // ---- general-F network (gnet.hip.h): operand layouts, buffers, launch sequence -----------------------------------
+// ---- operands of net_x3.hip.h: every weight as three bf16 planes (w = w1 + w2 + w3 exactly), in A-operand lane order ----
+static uint16_t bf16_rne(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf16_value(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static void bf16_split3(float v, uint16_t out[3]) {
+    out[0] = bf16_rne(v);
+    float r = v - bf16_value(out[0]);
+    out[1] = bf16_rne(r);
+    r = r - bf16_value(out[1]);
+    out[2] = bf16_rne(r);
+}
 template <class G>
 static int gnet_reserve(bb_engine *e, int n) {
     using GG = GNetGeom<G>;
@@ -543,9 +566,14 @@ static int gnet_reserve(bb_engine *e, int n) {
     if (cap <= g.cap) return BB_OK;
     HIPCHK(sync_all(e));
     size_t pos_floats = (size_t)g.NCB * 4 * GG::PLANE;
-    if (dalloc(e, g.inp, (size_t)cap * GG::SLOTS * GG::CP) || dalloc(e, g.act[0], (size_t)cap * pos_floats) ||
-        dalloc(e, g.act[1], (size_t)cap * pos_floats))
+    if (dalloc(e, g.inp, (size_t)cap * GG::SLOTS * GG::CP) || dalloc(e, g.act[0], (size_t)cap * pos_floats))
         return BB_ERR_HIP; // zero-filled: the halo ring of every position stays zero for the buffers' lifetime
+    if (e->gx3.wt) { // bf16-pipe tower: two buffers of three bf16 planes; the float32 buffer above only carries the last layer
+        const size_t pos_bytes = (size_t)g.NCB * GG::SLOTS * 96;
+        if (dalloc(e, e->gx3.act3[0], (size_t)cap * pos_bytes) || dalloc(e, e->gx3.act3[1], (size_t)cap * pos_bytes)) return BB_ERR_HIP;
+    } else if (dalloc(e, g.act[1], (size_t)cap * pos_floats)) {
+        return BB_ERR_HIP;
+    }
     HIPCHK(sync_all(e)); // the fills ran on the engine stream; the caller may launch on another one
     g.cap = cap;
     return BB_OK;
@@ -604,6 +632,43 @@ static int load_general_weights(bb_engine *e, const bb_net_weights *w) {
     g.w0 = d_w0;
     g.wt = (const f32x4 *)d_wt;
     g.epi = d_epi;
+    // the tower layers' operands as three bf16 planes (gnet_x3.hip.h); BB_NET_X3=0 keeps the float32-MFMA layers
+    const bool want3 = R > 0 && !(getenv("BB_NET_X3") && atoi(getenv("BB_NET_X3")) == 0);
+    if (want3) {
+        static const int slice_taps[4][2] = {{0, 1}, {3, 4}, {6, 7}, {2, 5}};
+        const size_t per = GX3_PAIR_B / 2; // uint16 elements per (fb, cb) block
+        std::vector<uint16_t> x((size_t)2 * R * NCB * NCB * per);
+        uint16_t h[3];
+        for (int l = 0; l < 2 * R; l++)
+            for (int fb = 0; fb < NCB; fb++)
+                for (int cb = 0; cb < NCB; cb++) {
+                    uint16_t *o = x.data() + (((size_t)l * NCB + fb) * NCB + cb) * per;
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int f = lane & 15, gg = lane >> 4;
+                        for (int sl = 0; sl < 4; sl++)
+                            for (int i = 0; i < 8; i++) {
+                                int tap = slice_taps[sl][gg >> 1], c = 16 * cb + 8 * (gg & 1) + i;
+                                bf16_split3(w->blk_k[(((size_t)l * 9 + tap) * F + c) * F + 16 * fb + f], h);
+                                for (int q = 0; q < 3; q++) o[(((size_t)sl * 3 + q) * 64 + lane) * 8 + i] = h[q];
+                            }
+                        for (int i = 0; i < 4; i++) {
+                            bf16_split3(w->blk_k[(((size_t)l * 9 + 8) * F + 16 * cb + 4 * gg + i) * F + 16 * fb + f], h);
+                            for (int q = 0; q < 3; q++) o[(size_t)4 * 3 * 64 * 8 + ((size_t)q * 64 + lane) * 4 + i] = h[q];
+                        }
+                    }
+                }
+        unsigned char *d_x = (unsigned char *)e->gx3.wt;
+        if (!d_x || x.size() * 2 != e->gx3_bytes) {
+            if (dalloc(e, d_x, x.size() * 2 + 16, false)) return BB_ERR_HIP;
+            e->gx3_bytes = x.size() * 2;
+            g.cap = 0; // (the activation buffers of the other form are re-reserved on the next launch)
+        }
+        HIPCHK(hipMemcpy(d_x, x.data(), x.size() * 2, hipMemcpyHostToDevice));
+        e->gx3.wt = d_x;
+    } else {
+        if (e->gx3.wt) g.cap = 0;
+        e->gx3.wt = nullptr;
+    }
     return BB_OK;
 }
 
@@ -626,6 +691,38 @@ static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slo
         g.act[1] += (size_t)buf_offset * pos_floats;
     }
     k_gnet_input<G><<<nblk((size_t)n_max * GG::HW), 256, 0, st>>>(g, n_max, n_ptr, slot_list, states, planes);
+    if (e->gx3.wt) { // tower layers on the bf16 matrix pipe (gnet_x3.hip.h); first conv in float32 MFMA, writing the split form
+        GNetX3 gx = e->gx3;
+        const size_t pos_bytes = (size_t)g.NCB * GG::SLOTS * 96;
+        gx.act3[0] += (size_t)buf_offset * pos_bytes;
+        gx.act3[1] += (size_t)buf_offset * pos_bytes;
+        const int L = 2 * g.R;
+        if ((long)n_max * g.NCB <= 2048 && !n_ptr) { // small batch: one position x one filter block per wave
+            const int ppw = g.NCB >= 4 ? 4 : (g.NCB >= 2 ? 2 : 1);
+            dim3 grid((n_max + 4 / ppw - 1) / (4 / ppw), (g.NCB + ppw - 1) / ppw);
+            k_gnet_conv<G, true, 1, 1><<<grid, 256, 0, st>>>(g, 0, n_max, n_ptr, nullptr, g.act[0], 0, ppw, gx.act3[0]);
+            for (int l = 0; l < L; l++) {
+                if (l + 1 < L) k_gnet_conv_x3<G, 1, 1, false><<<grid, 256, 0, st>>>(g, gx, 1 + l, n_max, n_ptr, gx.act3[l & 1], gx.act3[(l & 1) ^ 1], nullptr, l & 1, ppw);
+                else k_gnet_conv_x3<G, 1, 1, true><<<grid, 256, 0, st>>>(g, gx, 1 + l, n_max, n_ptr, gx.act3[l & 1], gx.act3[(l & 1) ^ 1], g.act[0], l & 1, ppw);
+            }
+        } else {
+            constexpr int FBW3 = 4;
+            const int fgroups = (g.NCB + FBW3 - 1) / FBW3;               // groups of 4 filter blocks
+            const int gpw = fgroups >= 4 ? 4 : (fgroups >= 2 ? 2 : 1);   // ... per workgroup
+            const int groups = (n_max + GG::PPB - 1) / GG::PPB;          // groups of PPB positions
+            dim3 grid((groups + 4 / gpw - 1) / (4 / gpw), (fgroups + gpw - 1) / gpw);
+            {
+                const int pairs = (g.NCB + GN_FBW - 1) / GN_FBW;
+                const int ppw = pairs >= 4 ? 4 : (pairs >= 2 ? 2 : 1);
+                dim3 grid0((groups + 4 / ppw - 1) / (4 / ppw), (pairs + ppw - 1) / ppw);
+                k_gnet_conv<G, true><<<grid0, 256, 0, st>>>(g, 0, n_max, n_ptr, nullptr, g.act[0], 0, ppw, gx.act3[0]);
+            }
+            for (int l = 0; l < L; l++) {
+                if (l + 1 < L) k_gnet_conv_x3<G, GG::PPB, FBW3, false><<<grid, 256, 0, st>>>(g, gx, 1 + l, n_max, n_ptr, gx.act3[l & 1], gx.act3[(l & 1) ^ 1], nullptr, l & 1, gpw);
+                else k_gnet_conv_x3<G, GG::PPB, FBW3, true><<<grid, 256, 0, st>>>(g, gx, 1 + l, n_max, n_ptr, gx.act3[l & 1], gx.act3[(l & 1) ^ 1], g.act[0], l & 1, gpw);
+            }
+        }
+    } else
     if ((long)n_max * g.NCB <= 2048 && !n_ptr) {
         // small batch: one position x one filter block per wave (latency of a lone evaluation: 40 layers x ~25 us
         // instead of x ~170 us at 256 filters)
@@ -649,26 +746,6 @@ static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slo
     return BB_OK;
 }
 
-// ---- operands of net_x3.hip.h: every weight as three bf16 planes (w = w1 + w2 + w3 exactly), in A-operand lane order ----
-static uint16_t bf16_rne(float v) {
-    uint32_t u;
-    memcpy(&u, &v, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-static float bf16_value(uint16_t h) {
-    uint32_t u = (uint32_t)h << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-static void bf16_split3(float v, uint16_t out[3]) {
-    out[0] = bf16_rne(v);
-    float r = v - bf16_value(out[0]);
-    out[1] = bf16_rne(r);
-    r = r - bf16_value(out[1]);
-    out[2] = bf16_rne(r);
-}
 // w0:   [plane][lane][8] (taps 2g, 2g + 1 x 4 input planes) then [plane][lane][4] (tap 8, lane group 0 only)
 // wt12: per layer [slice 0..3][plane 0..1][lane][8] (slices = taps (0,1), (3,4), (6,7), (2,5); lane group g: tap g >> 1 of the
 //       slice, channels 8 (g & 1) .. + 7) then [plane 0..1][lane][4] (tap 8, channels 4g .. 4g + 3)

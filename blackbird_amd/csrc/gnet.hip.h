@@ -74,9 +74,11 @@ __global__ void __launch_bounds__(256) k_gnet_input(GNetDev gd, int n_max, const
 // PPB / FBW are template parameters so that a SMALL batch (a single FindMove position, an arena of a few games) can be cut
 // finely -- one position and one filter block per wave: 16x more waves, each with 1/7 of the MFMAs -- instead of
 // leaving 250 CUs idle behind two fat workgroups.
+// out3 != nullptr (first conv only): the outputs are written as three bf16 planes, [pos][cb][slot][plane][16 ch], for the
+// bf16-pipe tower layers (gnet_x3.hip.h) instead of the float32 layout.
 template <class G, bool FIRST, int PPB = GNetGeom<G>::PPB, int FBW = GN_FBW>
 __global__ void __launch_bounds__(256) k_gnet_conv(GNetDev gd, int layer, int n_max, const int *n_ptr, const float *in,
-                                                   float *out, int skip, int pairs_per_wg) {
+                                                   float *out, int skip, int pairs_per_wg, unsigned char *out3 = nullptr) {
     using GG = GNetGeom<G>;
     constexpr int HW = GG::HW, W = GG::W, SLOTS = GG::SLOTS, CP = GG::CP, NT = (PPB * HW + 15) / 16, PLANE = GG::PLANE,
                   CIN = GG::CIN, STEPS0 = GG::STEPS0;
@@ -203,6 +205,31 @@ __global__ void __launch_bounds__(256) k_gnet_conv(GNetDev gd, int layer, int n_
                 float v = __builtin_fmaf(acc[f][t][r], scale[r], shift[r]);
                 if (skip) v = v + sk[r];
                 y[r] = fmaxf(v, 0.f);
+            }
+            if constexpr (FIRST) {
+                if (out3) {
+                    if (valid[t]) {
+                        int q = t * 16 + nn, pp = q / HW, cell = q % HW, yy = cell / W, xx = cell % W;
+                        unsigned char *o = out3 + ((size_t)(pos0 + pp) * NCB + fbs[f]) * (SLOTS * 96) + ((yy + 1) * (W + 1) + (xx + 1)) * 96 + j * 8;
+                        unsigned a[4], b[4], c[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            __bf16 h1 = (__bf16)y[r];
+                            a[r] = (unsigned)__builtin_bit_cast(unsigned short, h1);
+                            float r1 = y[r] - __uint_as_float(a[r] << 16);
+                            __bf16 h2 = (__bf16)r1;
+                            b[r] = (unsigned)__builtin_bit_cast(unsigned short, h2);
+                            float r2 = r1 - __uint_as_float(b[r] << 16);
+                            __bf16 h3 = (__bf16)r2;
+                            c[r] = (unsigned)__builtin_bit_cast(unsigned short, h3);
+                        }
+                        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+                        *(u2 *)(o) = u2{a[0] | (a[1] << 16), a[2] | (a[3] << 16)};
+                        *(u2 *)(o + 32) = u2{b[0] | (b[1] << 16), b[2] | (b[3] << 16)};
+                        *(u2 *)(o + 64) = u2{c[0] | (c[1] << 16), c[2] | (c[3] << 16)};
+                    }
+                    continue;
+                }
             }
             if (valid[t]) *(f32x4 *)(op + ooff[t] + fo) = y;
         }

@@ -29,7 +29,8 @@ def _check(orc, game, F, R, n, seed, perturb=True):
     assert np.max(np.abs(v1 - ov)) <= TOL
     assert np.max(np.abs(l1 - ol) / np.maximum(1.0, np.abs(ol))) <= TOL
     assert np.max(np.abs(p1 - op)) <= TOL
-    assert np.mean(l1 == ol) > 0.99  # same K order as the oracle's fmaf chains
+    if eng.net_form() == 1 and os.environ.get("BB_NET_X3") == "0":
+        assert np.mean(l1 == ol) > 0.99  # float32-MFMA layers: the K order of the oracle's fmaf chains
     perm = rng.permutation(n)  # batch invariance, also across workgroup boundaries
     v3, l3, p3 = eng.net_eval(states=st[perm])
     assert np.array_equal(v3, v1[perm]) and np.array_equal(l3, l1[perm]) and np.array_equal(p3, p1[perm])
