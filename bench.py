@@ -321,7 +321,7 @@ def main():
         elif mode == 5:
             kernel = "k_dc_selfplay_fused (one wave per game: tree step, network and move in the same wave)"
         elif w["filters"] != 16:
-            kernel = "k_gnet_conv<%s,false,4,2> x %d conv layers + first conv + heads per evaluation batch" % (gname, 2 * w["blocks"])
+            kernel = ("k_gnet_conv_x3<%s,4,4> (bf16 matrix pipe, float32 by 3-way operand split)" if form == 3 else "k_gnet_conv<%s,false,4,2>") % gname + " x %d conv layers + first conv + heads per evaluation batch" % (2 * w["blocks"])
         else:
             kernel = (f"k_net_x3<{gname}>" if form == 2 else f"k_net_compact<{gname},4>" if mode == 1 else f"k_net_fused16<{gname}>")
         if mode >= 2:
@@ -336,7 +336,8 @@ def main():
         # The roof of the arithmetic actually issued.  float32 MFMA forms: the f32 MFMA peak.  Split-operand form: every
         # float32 product is six bf16 MFMA products, so the ceiling for float32-equivalent FLOP/s is the bf16 peak / 6
         # (416.7 TFLOP/s); `achieved` stays the ALGORITHMIC float32 FLOPs of SURVEY.md 8d either way.
-        peak = PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS if form == 2 else PEAK_F32_MFMA_TFLOPS
+        x3 = form in (2, 3)
+        peak = PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS if x3 else PEAK_F32_MFMA_TFLOPS
         mean_depth = cnt["sum_depth"] / max(cnt["sims"], 1)
         a_c = 7.0 if gname == "Connect4" else 14.6   # DragonChess: mean legal count of SURVEY.md 6 [probe]
         b_sim = tree_bytes_per_sim(w, mean_depth, a_c)
@@ -349,7 +350,7 @@ def main():
             "metric": "selfplay_games_per_sec", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / max(K, 1) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (float32 operands split exactly into 3 bf16 values, 6 bf16 MFMA products each, f32 accumulate)" if form == 2 else "f32",
+            "dtype": "f32 (float32 operands split exactly into 3 bf16 values, 6 bf16 MFMA products each, f32 accumulate)" if x3 else "f32",
             "data": "synthetic (self-play from the initial position, random-init weights seed 0)",
             "config": {"workload": "%s, DynamicMCTS %d sims/move, %d concurrent games per GPU, net R%d/F%d/D16 fp32, "
                                    "noise alpha 0.2 eps 0.3 (BASELINE configs[%d])"
@@ -372,7 +373,7 @@ def main():
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "peak_note": ("bf16 MFMA dense peak 2500 / 6 products per float32 product; against the float32 MFMA "
                                        "peak (157.3) the same algorithmic rate is %.3f" % (achieved / PEAK_F32_MFMA_TFLOPS))
-                                      if form == 2 else "float32 MFMA dense peak",
+                                      if x3 else "float32 MFMA dense peak",
                          "bf16_tflops_issued": (achieved * X3_PRODUCTS * 48.0 / 42.0) if (form == 2 and gname == "Connect4") else None,
                          "traffic": (traffic_rate * net_ms * 1e-3) if (mode >= 2 and traffic_rate) else None,
                          "traffic_note": ("HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) rate from profiles/%s x this "

@@ -341,7 +341,8 @@ class Engine:
         return check(lib().bb_selfplay_mode(self.h))
 
     def net_form(self):
-        """0 float32-MFMA fused tower, 1 general-filter launches, 2 float32 results on the bf16 matrix pipe (bb_net_form)."""
+        """0 float32-MFMA fused tower, 1 general-filter launches, 2 fused tower on the bf16 matrix pipe (float32 by operand
+        splitting), 3 general-filter launches with such tower layers (bb_net_form)."""
         return check(lib().bb_net_form(self.h))
 
     def timing_net(self, iters=50, noise=True, ablate=0):

@@ -506,7 +506,8 @@ extern "C" int bb_timing_read(bb_engine *e, double *mean_ms_out, double *min_ms_
 extern "C" int bb_net_form(bb_engine *e) {
     if (!e) return fail(BB_ERR_ARG, "null engine");
     if (!e->has_weights) return fail(BB_ERR_WEIGHTS, "bb_load_weights has not been called");
-    return e->general_net ? 1 : (e->x3.w0 ? 2 : 0);
+    if (e->general_net) return e->gx3.wt ? 3 : 1;
+    return e->x3.w0 ? 2 : 0;
 }
 
 extern "C" int bb_selfplay_mode(bb_engine *e) {

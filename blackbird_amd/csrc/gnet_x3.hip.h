@@ -28,6 +28,8 @@ struct GNetX3 {
     unsigned char *act3[2];  // [cap][NCB][SLOTS][96]
 };
 
+// (Measured and dropped: the activation operand of a slice fetched once per workgroup into a double-buffered LDS image and
+// read back by its four waves -- 47.1 ms against 40.1 ms per 20 x 256 batch; the L1 rate was not the limit.)
 template <class G, int PPB, int FBW, bool LAST>
 __global__ void __launch_bounds__(256) k_gnet_conv_x3(GNetDev gd, GNetX3 gx, int layer, int n_max, const int *n_ptr,
                                                       const unsigned char *in, unsigned char *out3, float *outf, int skip,
@@ -85,16 +87,22 @@ __global__ void __launch_bounds__(256) k_gnet_conv_x3(GNetDev gd, GNetX3 gx, int
 #pragma unroll
         for (int f = 0; f < FBW; f++)
 #pragma unroll
-            for (int q = 0; q < 3; q++) w[f][q] = *(const bf16x8 *)(wp[f] + (size_t)cb * GX3_PAIR_B + ((s * 3 + q) * 64 + lane) * 16);
+            for (int q = 0; q < 3; q++) w[f][q] = *(const bf16x8 *)(wp[f] + (size_t)cb * GX3_PAIR_B + (s * 3 + q) * 1024 + (unsigned)(lane * 16));
     };
+    // The slice-dependent part of an operand address is wave-uniform: it goes into the (scalar) base, the per-lane part is a
+    // 32-bit offset register that never changes -- a load is then ONE instruction (saddr + voffset).  With the slice offset
+    // added per lane every load carried 6 vector instructions, ~250 per slice in bursts between the MFMA groups.
     auto load_x = [&](bf16x8 (&p)[NT], int u, int plane) __attribute__((always_inline)) {
         const int cb = u >> 2, s = u & 3;
         const unsigned char *b = ip + (size_t)cb * cb_bytes + plane * 32;
+        if (s < 3) {
+            const unsigned char *bs = b + s * (W + 1) * SB;
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            // (s is a runtime value here: both candidate offsets are formed and one is selected)
-            int o = s < 3 ? aA[t] + s * (W + 1) * SB : aB[t] + 2 * SB;
-            p[t] = *(const bf16x8 *)(b + o);
+            for (int t = 0; t < NT; t++) p[t] = *(const bf16x8 *)(bs + (unsigned)aA[t]);
+        } else {
+            const unsigned char *bs = b + 2 * SB;
+#pragma unroll
+            for (int t = 0; t < NT; t++) p[t] = *(const bf16x8 *)(bs + (unsigned)aB[t]);
         }
     };
     auto mma = [&](const bf16x8 (&w)[FBW][3], int q, const bf16x8 (&p)[NT]) __attribute__((always_inline)) {
@@ -104,6 +112,8 @@ __global__ void __launch_bounds__(256) k_gnet_conv_x3(GNetDev gd, GNetX3 gx, int
             for (int f = 0; f < FBW; f++) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[f][q], p[t], acc[f][t], 0, 0, 0);
     };
     // one slice with its plane 1 in `pa`: plane 2 -> pb, plane 3 -> pa, the next slice's plane 1 -> pb, its weights -> wn
+    // (Measured and dropped: touching the next channel block's cache lines a slice and a half ahead -- one dword per 128-byte
+    // line, values unused -- 45-50 ms against 38.8 ms per 20 x 256 batch.)
     auto slice = [&](const bf16x8 (&w)[FBW][3], bf16x8 (&wn)[FBW][3], bf16x8 (&pa)[NT], bf16x8 (&pb)[NT], int u) __attribute__((always_inline)) {
         const int un = u + 1 < steps ? u + 1 : u;
         load_x(pb, u, 1);

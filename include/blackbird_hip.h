@@ -178,7 +178,8 @@ int bb_selfplay_mode(bb_engine *e);
  * tower (bit-identical to the k-ordered fmaf chain); 1 float32 MFMA, one launch per conv layer (any multiple of 16
  * filters); 2 float32 results on the bf16 matrix pipe -- every operand split exactly into three bf16 values, six MFMA
  * products per K slice, float32 accumulation (16-filter networks of Connect4 / TicTacToe; 1e-5 of form 0, not
- * bit-identical; the environment variable BB_NET_X3=0 selects form 0 instead).  Negative: BB_ERR_*. */
+ * bit-identical; the environment variable BB_NET_X3=0 selects form 0 instead); 3 the launch-per-layer network with its tower
+ * layers in the split-operand form of 2 (BB_NET_X3=0: form 1).  Negative: BB_ERR_*. */
 int bb_net_form(bb_engine *e);
 
 /* Network.getEvaluation + getPolicy for n positions (Network.py:48-64; graph NetworkFactory.py:22-183).
