@@ -198,3 +198,46 @@ def test_every_positions_per_wave_variant_matches_oracle(orc, monkeypatch, game,
         assert np.array_equal(l[:k], ol[:k]), (cnt, float(np.abs(l[:k] - ol[:k]).max()))
         assert np.max(np.abs(v[:k] - ov[:k])) <= TOL and np.max(np.abs(p[:k] - op[:k])) <= TOL
     eng.close()
+
+
+@pytest.mark.parametrize("game", [_lib.GAME_CONNECT4, _lib.GAME_TICTACTOE])
+def test_split_operand_tower_every_tap_and_plane_contributes(game):
+    """The bf16-pipe tower (net_x3.hip.h) forms a float32 product from three bf16 planes per operand.  A weight 1 + 2^-10 + 2^-20
+    has one bit in each plane; placed on one tap of the first conv (a network without residual blocks, identity batch norm) the
+    value head sees it only if that tap's slice carried all three planes.  The first version lost plane 2 of every K = 32 slice:
+    a K = 32 MFMA directly followed by a K = 16 MFMA on the same accumulator reads its SrcC too early on gfx950 / ROCm 7.2
+    (x3_mfma_switch).  Checked through the public outputs: the value of an empty board equals the float64 statement within
+    1e-6 only when nothing is lost (a lost plane 2 costs 1e-3)."""
+    gi = _lib.game_info(game)
+    H, Wd, _ = _lib.GRID[game]
+    st = _lib.pack_grid(game, np.zeros((1, H, Wd, 2), dtype=np.int8), np.ones(1, dtype=np.int64))  # empty board, player 1: plane 2 = +1
+    planes = _lib.game_encode(game, st)
+    K = "resTower/conv_block/conv/kernel"
+    wv = 1 + 2.0 ** -10 + 2.0 ** -20
+    for tap in range(9):
+        w = W.init_weights(gi.C, 16, 0, 16, gi.A, seed=11)
+        w[K][:] = 0
+        w[K][tap // 3, tap % 3, 2, 0] = wv
+        w["resTower/conv_block/conv/bias"][:] = 0
+        for s, v in (("gamma", 1), ("beta", 0), ("moving_mean", 0), ("moving_variance", 1 - 1e-3)):
+            w["resTower/conv_block/batch_norm/" + s][:] = v
+        eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)
+        eng.load_weights(W.flatten(w))
+        assert eng.net_form() == 2
+        v, l, p = eng.net_eval(planes=planes)
+        eng.close()
+        # float64 statement: channel 0 of the first conv = wv where the tap's neighbour is on the board, pooled value head after it
+        dy, dx = tap // 3 - 1, tap % 3 - 1
+        inside = sum(1 for y in range(H) for x in range(Wd) if 0 <= y + dy < H and 0 <= x + dx < Wd)
+        x0 = np.zeros(16)
+        vk = w["value/convolution/kernel"].astype(np.float64).reshape(16)
+        g_, be, mu, var = [w["value/batch_norm/" + s].astype(np.float64)[0] for s in ("gamma", "beta", "moving_mean", "moving_variance")]
+        pre_on = wv * vk[0] + float(w["value/convolution/bias"][0])
+        pre_off = float(w["value/convolution/bias"][0])
+        bn = lambda a: max((a - mu) / np.sqrt(var + 1e-3) * g_ + be, 0.0)
+        R = inside * bn(pre_on) + (H * Wd - inside) * bn(pre_off)
+        d1k = w["value/dense_1/kernel"].astype(np.float64).reshape(-1); d1b = w["value/dense_1/bias"].astype(np.float64)
+        hdn = np.maximum(R * d1k + H * Wd * d1b, 0.0)
+        expect = np.tanh(hdn @ w["value/dense_2/kernel"].astype(np.float64).reshape(-1) + float(w["value/dense_2/bias"][0]))
+        assert abs(float(v[0]) - expect) <= 1e-6, (tap, float(v[0]), expect)
+        del x0
