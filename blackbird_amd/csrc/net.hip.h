@@ -99,15 +99,36 @@ template <int HW>
 __device__ __forceinline__ float wide_prob(const WideHead &h, float k0, float k1, float b) {
     return wide_expterm(wide_logit<HW>(h.R0, h.R1, k0, k1, b), h.m) * h.inv;
 }
+// Wave-wide reductions without LDS traffic (all 64 lanes active).  The sum is the xor butterfly with strides 1, 2, 4, 8, 16,
+// 32 -- the adjacent-pairs tree ((x0 + x1) + (x2 + x3)) + ... that the oracle's tree_sum64 folds in the same order: strides 1
+// and 2 are quad permutes; for 4 and 8 the mirrored lane (7 - i, 15 - i) lies in the other quad / half, whose lanes all hold
+// the same partial sum by then; after that the four rows are uniform and (r0 + r1) + (r2 + r3) is what strides 16 and 32 form
+// on every lane.  (Six ds_bpermute round trips each before: ~2 k cycles per evaluation in the heads.)
+__device__ __forceinline__ float dpp_f32(float v, int ctrl_sel) {
+    const int i = __float_as_int(v);
+    int r;
+    switch (ctrl_sel) {
+    case 0: r = __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xf, 0xf, false); break;  // quad_perm [1,0,3,2]
+    case 1: r = __builtin_amdgcn_update_dpp(i, i, 0x4E, 0xf, 0xf, false); break;  // quad_perm [2,3,0,1]
+    case 2: r = __builtin_amdgcn_update_dpp(i, i, 0x141, 0xf, 0xf, false); break; // row_half_mirror
+    default: r = __builtin_amdgcn_update_dpp(i, i, 0x140, 0xf, 0xf, false); break; // row_mirror
+    }
+    return __int_as_float(r);
+}
+__device__ __forceinline__ float lane_f32(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 __device__ __forceinline__ float wave_max_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f32(v, 0));
+    v = fmaxf(v, dpp_f32(v, 1));
+    v = fmaxf(v, dpp_f32(v, 2));
+    v = fmaxf(v, dpp_f32(v, 3));
+    return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
 __device__ __forceinline__ float wave_sum_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32(v, 0);
+    v += dpp_f32(v, 1);
+    v += dpp_f32(v, 2);
+    v += dpp_f32(v, 3);
+    return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 // max and 1 / sum(exp) of the A logits, lanes striding the actions (lane + 64 k, k ascending; partial sums per lane in
 // that order, then the xor butterflies) -- the order the dense form uses.  PK: pointer type of the head weights
@@ -160,7 +181,7 @@ __device__ __forceinline__ void wide_head_stats(WideHead &h, PK pdk, PK pdb, int
 // holds both against each other and against PyTorch) and the oracle's orc_net_forward restates THIS form -- sums as the
 // fixed pairwise tree below -- so that GPU and oracle logits stay bit-identical.
 //
-// reduce_sum over H, W of one position: pixel p on lane p (lanes >= H*W hold 0.0), xor butterfly with strides 32 ... 1.
+// reduce_sum over H, W of one position: pixel p on lane p (lanes >= H*W hold 0.0), xor butterfly with strides 1 ... 32.
 // Every lane ends with the same bits; the tree does not depend on how positions are packed into waves.
 __device__ __forceinline__ float pooled_sum(float v) { return wave_sum_f32(v); }
 
@@ -267,7 +288,7 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
             float r = (nd.dbg & 8) ? nd.alpha : -1.0f;
             for (uint32_t k = 0; k < 32 && __any(drawing && r < 0.0f); k += 2) {
                 float mine = (drawing && r < 0.0f) ? bb_beta_pair(nd.seed, gid, ser, (uint32_t)q, ia, ib, k + sub) : -1.0f;
-                float other = __shfl_xor(mine, 1, 64);
+                float other = dpp_f32(mine, 0); // the pair's other lane (quad permute, no LDS round trip)
                 float first = sub ? other : mine, second = sub ? mine : other; // pair k before pair k+1
                 if (r < 0.0f) r = first >= 0.0f ? first : second;
             }

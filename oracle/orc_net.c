@@ -85,13 +85,13 @@ static void conv3x3(const float *in, float *out, const float *skip, int H, int W
 }
 
 /* reduce_sum over H, W as a fixed pairwise tree: the values sit in slots 0..n-1 of a 64-slot vector (the rest 0.0) and are
- * folded with strides 32, 16, ..., 1 -- the xor butterfly of a 64-lane wave, which is how the HIP kernels form the sum
- * (blackbird_amd/csrc/net.hip.h: pooled_sum).  TensorFlow leaves the order of a reduce_sum unspecified. */
+ * folded with strides 1, 2, ..., 32 (adjacent pairs first) -- the xor butterfly of a 64-lane wave in the order the HIP
+ * kernels form it (blackbird_amd/csrc/net.hip.h: wave_sum_f32).  TensorFlow leaves the order of a reduce_sum unspecified. */
 static float tree_sum64(const float *x, int n, int stride) {
     float t[64];
     for (int i = 0; i < 64; i++) t[i] = i < n ? x[(size_t)i * stride] : 0.f;
-    for (int o = 32; o >= 1; o >>= 1)
-        for (int i = 0; i < o; i++) t[i] = t[i] + t[i + o];
+    for (int o = 1; o < 64; o <<= 1)
+        for (int i = 0; i < 64; i += 2 * o) t[i] = t[i] + t[i + o];
     return t[0];
 }
 
