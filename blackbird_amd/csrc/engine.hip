@@ -188,7 +188,7 @@ struct bb_engine {
     DCEdges edges; // DragonChess only
     int32_t *d_child_action = nullptr;
     NetDev net;
-    NetX3 x3 = {nullptr, nullptr, nullptr}; // 16-filter network of a dense game on the bf16 matrix pipe (net_x3.hip.h); null: float32 MFMA path
+    NetX3 x3 = {nullptr, nullptr, nullptr, nullptr}; // 16-filter network of a dense game on the bf16 matrix pipe (net_x3.hip.h); null: float32 MFMA path
     size_t x3_bytes = 0;
     bool has_weights = false;
     int net_F = 0, net_C = 0;
@@ -751,13 +751,16 @@ static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slo
 // wt12: per layer [slice 0..3][plane 0..1][lane][8] (slices = taps (0,1), (3,4), (6,7), (2,5); lane group g: tap g >> 1 of the
 //       slice, channels 8 (g & 1) .. + 7) then [plane 0..1][lane][4] (tap 8, channels 4g .. 4g + 3)
 // wt3:  per layer [slice][lane][8] then [lane][4]: the third plane alone
-static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vector<uint16_t> &wt12, std::vector<uint16_t> &wt3) {
+// wt8:  per layer [plane][lane][8]: tap 8 as a K = 32 slice, lane groups 0, 1 = channels 0..7, 8..15, groups 2, 3 zero
+static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vector<uint16_t> &wt12, std::vector<uint16_t> &wt3,
+                    std::vector<uint16_t> &wt8) {
     const int F = 16, C = w->C, R = w->R;
     const bool wide = C > 4; // DragonChess: one K = 32 slice per tap, lane group g = input planes 8g .. 8g + 7
     w0.assign(wide ? (size_t)9 * 3 * 64 * 8 : (size_t)(3 * 64 * 8 + 3 * 64 * 4), 0);
     const size_t per12 = 4 * 2 * 64 * 8 + 2 * 64 * 4, per3 = 4 * 64 * 8 + 64 * 4;
     wt12.assign((size_t)2 * R * per12, 0);
     wt3.assign((size_t)2 * R * per3, 0);
+    wt8.assign((size_t)2 * R * 3 * 64 * 8, 0);
     uint16_t h[3];
     for (int lane = 0; wide && lane < 64; lane++) {
         const int f = lane & 15, g = lane >> 4;
@@ -796,6 +799,10 @@ static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vec
                 bf16_split3(w->blk_k[(((size_t)l * 9 + 8) * F + (4 * g + i)) * F + f], h);
                 for (int q = 0; q < 2; q++) o12[(size_t)4 * 2 * 64 * 8 + ((size_t)q * 64 + lane) * 4 + i] = h[q];
                 o3[(size_t)4 * 64 * 8 + (size_t)lane * 4 + i] = h[2];
+            }
+            for (int i = 0; i < 8 && g < 2; i++) {
+                bf16_split3(w->blk_k[(((size_t)l * 9 + 8) * F + (8 * g + i)) * F + f], h);
+                for (int q = 0; q < 3; q++) wt8[(((size_t)l * 3 + q) * 64 + lane) * 8 + i] = h[q];
             }
         }
     }
@@ -881,9 +888,9 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     {
         const bool want = F == 16 && C <= 32 && !e->general_net && !(getenv("BB_NET_X3") && atoi(getenv("BB_NET_X3")) == 0);
         if (want) {
-            std::vector<uint16_t> xw0, xw12, xw3;
-            pack_x3(w, xw0, xw12, xw3);
-            const size_t b0 = xw0.size() * 2, b12 = xw12.size() * 2, b3 = xw3.size() * 2, bytes = b0 + b12 + b3;
+            std::vector<uint16_t> xw0, xw12, xw3, xw8;
+            pack_x3(w, xw0, xw12, xw3, xw8);
+            const size_t b0 = xw0.size() * 2, b12 = xw12.size() * 2, b3 = xw3.size() * 2, b8 = xw8.size() * 2, bytes = b0 + b12 + b3 + b8;
             unsigned char *d_x = (unsigned char *)e->x3.w0;
             if (!d_x || bytes != e->x3_bytes) {
                 if (dalloc(e, d_x, bytes + 16, false)) return BB_ERR_HIP;
@@ -892,11 +899,13 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
             HIPCHK(hipMemcpy(d_x, xw0.data(), b0, hipMemcpyHostToDevice));
             if (b12) HIPCHK(hipMemcpy(d_x + b0, xw12.data(), b12, hipMemcpyHostToDevice));
             if (b3) HIPCHK(hipMemcpy(d_x + b0 + b12, xw3.data(), b3, hipMemcpyHostToDevice));
+            if (b8) HIPCHK(hipMemcpy(d_x + b0 + b12 + b3, xw8.data(), b8, hipMemcpyHostToDevice));
             e->x3.w0 = d_x;
             e->x3.wt12 = d_x + b0;
             e->x3.wt3 = d_x + b0 + b12;
+            e->x3.wt8 = d_x + b0 + b12 + b3;
         } else {
-            e->x3.w0 = e->x3.wt12 = e->x3.wt3 = nullptr;
+            e->x3.w0 = e->x3.wt12 = e->x3.wt3 = e->x3.wt8 = nullptr;
         }
     }
     nd.R = R;

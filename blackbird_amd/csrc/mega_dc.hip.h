@@ -61,7 +61,7 @@ __device__ __attribute__((noinline)) void dc_fused_net_x3(const NetDev &nd_, con
     slot = as_lds(slot);
     nl = as_lds(nl);
     hl = as_lds(hl);
-    net_body_x3<DragonChess, false>(nd, x3, 1, 0, slot, (unsigned char *)nl, (const DCState *)d.leaf_state, nullptr, d.leaf_game_id,
+    net_body_x3<DragonChess, false, false, true>(nd, x3, 1, 0, slot, (unsigned char *)nl, (const DCState *)d.leaf_state, nullptr, d.leaf_game_id,
                                     d.leaf_serial, 0, nullptr, nullptr, nullptr, DragonChess::A, true, &hl->h);
     __threadfence_block();
 }
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
     using NG = NetGeom<DragonChess, 1>;
     // the tree's scratch (the 4032-float policy image) and the network's activations are never live together
     constexpr int TREE_BYTES = DC_LDS_FLOATS * 4;
-    constexpr int NET_BYTES = NG::WAVE_FLOATS * 4 > X3Geom<DragonChess>::WAVE_BYTES ? NG::WAVE_FLOATS * 4 : X3Geom<DragonChess>::WAVE_BYTES;
+    constexpr int NET_BYTES = NG::WAVE_FLOATS * 4 > X3Geom<DragonChess>::WAVE_BYTES_PP ? NG::WAVE_FLOATS * 4 : X3Geom<DragonChess>::WAVE_BYTES_PP;
     constexpr int WAVE_BYTES = ((TREE_BYTES > NET_BYTES ? TREE_BYTES : NET_BYTES) + 15) / 16 * 16;
     static_assert(4 * WAVE_BYTES + DC_HEAD_FLOATS * 4 + 1024 <= 163840, "four waves' scratch and the head weights must fit the 160 KiB LDS");
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[4][WAVE_BYTES];
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
     if (lane == 0) myslot[wv] = g;
 #ifdef BB_STAMPS
     float *lds = tl; // DST's accumulator sits past the policy image and the network's activations
-    static_assert(DC_STAMP_OFF >= NG::WAVE_FLOATS, "stamp words must survive the network's zeroing of its scratch");
+    static_assert(DC_STAMP_OFF >= NG::WAVE_FLOATS && DC_STAMP_OFF * 4 >= X3Geom<DragonChess>::WAVE_BYTES_PP, "stamp words must survive the network's zeroing of its scratch");
     if (lane < 16) ((unsigned long long *)(lds + DC_STAMP_OFF))[lane] = 0;
 #endif
     __threadfence_block();

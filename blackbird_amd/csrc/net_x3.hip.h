@@ -52,6 +52,7 @@ struct X3Geom {
     static constexpr int INP_B = WIDE_IN ? 0 : (SLOTS * 8 + 15) / 16 * 16; // wide inputs ([32 ch] bf16 = 64 B) sit in their X slot
     static constexpr int STATE_B = ((int)sizeof(typename G::State) + 15) / 16 * 16;
     static constexpr int WAVE_BYTES = X_B + INP_B + STATE_B;
+    static constexpr int WAVE_BYTES_PP = 2 * X_B + INP_B + STATE_B; // two activation buffers (net_body_x3 PP: DragonChess kernel)
     // packed weights (bytes).  A tower layer's first two planes (4 slices x 2 planes x 64 lanes x 16 B + tap 8: 2 planes x 64
     // lanes x 8 B) are what the persistent kernel keeps in LDS; the third plane (one product in six reads it) is a separate
     // array that every kernel streams from L2, a layer ahead -- with all three planes in LDS only 5 network waves fit a CU.
@@ -65,6 +66,7 @@ struct NetX3 {             // device pointers of the packed operands (nullptr: t
     const unsigned char *w0;   // X3Geom::W0_B
     const unsigned char *wt12; // [2R] x LAYER12_B   planes 1 and 2 of the tower weights
     const unsigned char *wt3;  // [2R] x LAYER3_B    plane 3, always read from global memory
+    const unsigned char *wt8;  // [2R] x 3 KB        tap 8 once more as a K = 32 slice ([plane][lane][16 B], lane groups 2, 3 zero): PP form
 };
 
 __device__ __forceinline__ unsigned bf16_bits(float v) { // round to nearest even, as v_cvt_pk_bf16_f32 does for finite values
@@ -104,7 +106,12 @@ __device__ __forceinline__ void x3_split4(const f32x4 y, u32x2 &p1, u32x2 &p2, u
 // LEAN: two network waves share each SIMD (12-wave persistent kernel, 168 VGPRs): the partner's MFMAs cover this wave's LDS
 // round trips, so operands are read tile by tile right where they are used instead of a phase ahead -- a third of the
 // operand registers.
-template <class G, bool WLDS, bool LEAN = false>
+// PP (with !WLDS; the caller provides X3Geom::WAVE_BYTES_PP): two activation buffers.  A lone wave per SIMD cannot hide its
+// epilogue (float32 -> three planes, ~35 vector instructions and three writes per tile) behind its own MFMAs while it
+// rewrites the buffer it reads; with a second buffer the layer runs tile by tile and tile t - 1's epilogue issues while
+// tile t's 30 MFMAs execute (a bf16 MFMA leaves 8 of its 16 cycles to the wave's vector instructions).  Tap 8 is a K = 32
+// slice with a zero upper half here, so the layer needs no switch between MFMA kinds.
+template <class G, bool WLDS, bool LEAN = false, bool PP = false>
 __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, int n, int pos0, const int *slot_list,
                                             unsigned char *wl, const typename G::State *states, const int8_t *planes,
                                             const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
@@ -115,9 +122,11 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     constexpr bool WIDE_IN = XG::WIDE_IN;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, nn = lane & 15, gh = g >> 1, gl = g & 1;
+    static_assert(!PP || !WLDS, "the two-buffer form keeps its weights in registers, a layer ahead");
     unsigned char *X = wl;
-    unsigned char *inp = wl + XG::X_B;
-    typename G::State *sst = (typename G::State *)(wl + XG::X_B + XG::INP_B);
+    unsigned char *X2 = wl + XG::X_B; // (PP only)
+    unsigned char *inp = wl + (PP ? 2 : 1) * XG::X_B;
+    typename G::State *sst = (typename G::State *)(wl + (PP ? 2 : 1) * XG::X_B + XG::INP_B);
     auto OI = [&](int pos) { return slot_list ? slot_list[pos] : pos; };
     const bool live = pos0 < n;
 #ifdef BB_STAMPS_NET
@@ -147,7 +156,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
                 shift0 = *(const f32x4 *)(nd.epi + 32 + 4 * g);
     if (zero_lds) {
         u32x4 z = {0u, 0u, 0u, 0u};
-        for (int i = lane; i < XG::WAVE_BYTES / 16; i += 64) ((u32x4 *)wl)[i] = z;
+        for (int i = lane; i < (PP ? XG::WAVE_BYTES_PP : XG::WAVE_BYTES) / 16; i += 64) ((u32x4 *)wl)[i] = z;
     }
     wave_lds_handover();
     if (!planes && lane == 0) *sst = my_state;
@@ -291,7 +300,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             for (int q = 0; q < 2; q++) w12c8[q] = *(const s16x4 *)(g12 + 4 * 2 * 64 * 16 + (q * 64 + lane) * 8);
         }
     };
-    if (L > 0) request_layer(0);
+    if (L > 0 && !PP) request_layer(0);
     auto conv_layer = [&](const int l, auto skip_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr bool SKIP = decltype(skip_tag)::value, LAST = decltype(last_tag)::value;
         const float *ep = nd.epi + (size_t)(1 + l) * 48;
@@ -448,6 +457,117 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
         }
         wave_lds_handover();
     };
+    // ---- the same layer, tile by tile, from buffer `src` into buffer `dst` (PP) -------------------------------------------------
+    // Two named sets of layer weights (15 operands each: 5 slices x 3 planes; slice 4 = tap 8 as a K = 32 slice): a layer
+    // computes from one set while the next layer's requests fill the other -- the block loop below alternates them, so no
+    // register copies are needed.
+    struct WSet { bf16x8 w1[5], w2[5], w3[5]; };
+    auto request_set = [&](WSet &ws, int l) __attribute__((always_inline)) {
+        const unsigned char *g12 = as_global(x3.wt12) + (size_t)l * XG::LAYER12_B, *g3 = as_global(x3.wt3) + (size_t)l * XG::LAYER3_B,
+                            *g8 = as_global(x3.wt8) + (size_t)l * 3 * 1024;
+#pragma unroll
+        for (int sl = 0; sl < 4; sl++) {
+            ws.w1[sl] = *(const bf16x8 *)(g12 + ((sl * 2 + 0) * 64 + lane) * 16);
+            ws.w2[sl] = *(const bf16x8 *)(g12 + ((sl * 2 + 1) * 64 + lane) * 16);
+            ws.w3[sl] = *(const bf16x8 *)(g3 + (sl * 64 + lane) * 16);
+        }
+        ws.w1[4] = *(const bf16x8 *)(g8 + (0 * 64 + lane) * 16);
+        ws.w2[4] = *(const bf16x8 *)(g8 + (1 * 64 + lane) * 16);
+        ws.w3[4] = *(const bf16x8 *)(g8 + (2 * 64 + lane) * 16);
+    };
+    auto conv_layer_pp = [&](const int l, const WSet &ws, const unsigned char *src, unsigned char *dst, auto skip_tag, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool SKIP = decltype(skip_tag)::value, LAST = decltype(last_tag)::value;
+        const float *ep = nd.epi + (size_t)(1 + l) * 48;
+        const f32x4 bias = *(const f32x4 *)(ep + 4 * g), scale = *(const f32x4 *)(ep + 16 + 4 * g), shift = *(const f32x4 *)(ep + 32 + 4 * g);
+        auto xoff = [&](int s, int t) __attribute__((always_inline)) { return s < 3 ? aA[t] + s * (W + 1) * SB : aB[t] + 2 * SB; };
+        constexpr int T8 = (2 * (W + 1) + 2) * SB;
+        // slice 4 = tap 8: lane groups 0, 1 hold its channels 0..7, 8..15; groups 2, 3 re-read them against zero weights
+        auto xaddr = [&](int s, int t) __attribute__((always_inline)) { return s < 4 ? xoff(s, t) : aA[t] - gh * SB + T8; };
+        // operands two slices ahead: a slice is 6 MFMAs = 96 cycles, an LDS round trip of three 1 KB reads is longer
+        bf16x8 xc[3], xn[3], xnn[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            xc[q] = *(const bf16x8 *)(src + xaddr(0, 0) + q * 32);
+            xn[q] = *(const bf16x8 *)(src + xaddr(1, 0) + q * 32);
+        }
+        auto epilogue = [&](int t) __attribute__((always_inline)) {
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = __builtin_fmaf(acc[t][r], scale[r], shift[r]);
+                if constexpr (SKIP) v = v + sk[t][r];
+                y[r] = fmaxf(v, 0.f);
+            }
+            if constexpr (SKIP) sk[t] = y;
+            if constexpr (LAST) {
+                *(f32x4 *)(dst + aO[t] + g * 8) = y;
+            } else {
+                u32x2 p1, p2, p3;
+                x3_split4(y, p1, p2, p3);
+                *(u32x2 *)(dst + aO[t]) = p1;
+                *(u32x2 *)(dst + aO[t] + 32) = p2;
+                *(u32x2 *)(dst + aO[t] + 64) = p3;
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            acc[t] = bias;
+            // One scheduling region per tile: its 30 MFMAs, the operand reads two slices ahead and tile t - 1's epilogue (~60 vector
+            // instructions, three writes), dealt out by the group barriers below: per slice three reads, then six times one MFMA
+            // and up to two vector instructions, which fit in the 8 cycles of its 16 that a bf16 MFMA leaves to the wave.
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                const int sn = (s + 2) % 5, tn = s + 2 < 5 ? t : t + 1;
+                if (tn < NT) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) xnn[q] = *(const bf16x8 *)(src + xaddr(sn, tn) + q * 32);
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w3[s], xc[0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w2[s], xc[1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[s], xc[2], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w2[s], xc[0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[s], xc[1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[s], xc[0], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    xc[q] = xn[q];
+                    xn[q] = xnn[q];
+                }
+            }
+            if (t > 0) epilogue(t - 1);
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); // DS read
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); // VALU
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0); // DS write
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        epilogue(NT - 1);
+        wave_lds_handover();
+    };
+    if constexpr (PP) {
+        // (the first conv wrote its planes into X; layers alternate X -> X2 -> X; the last one is odd and ends in X, where the heads read)
+        WSet wsa, wsb;
+        if (L > 0) request_set(wsa, 0);
+        for (int blk = 0; blk < R_eff; blk++) {
+            request_set(wsb, 2 * blk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            conv_layer_pp(2 * blk, wsa, X, X2, std::false_type{}, std::false_type{});
+            if (blk + 1 < R_eff) {
+                request_set(wsa, 2 * blk + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                conv_layer_pp(2 * blk + 1, wsb, X2, X, std::true_type{}, std::false_type{});
+            } else {
+                conv_layer_pp(2 * blk + 1, wsb, X2, X, std::true_type{}, std::true_type{});
+            }
+        }
+    } else
     for (int blk = 0; blk < R_eff; blk++) {
         conv_layer(2 * blk, std::false_type{}, std::false_type{});
         if (blk + 1 < R_eff) conv_layer(2 * blk + 1, std::true_type{}, std::false_type{});

@@ -55,7 +55,7 @@ struct DCEdges { // per-slot edge pool, stride edge_cap
 // diagnostic build: cycle stamps accumulate in the wave's LDS scratch (16 words past the policy image) and are flushed
 // once when the kernel ends, spread over 64 copies -- atomics inside the timed sections would sit in front of every
 // later s_waitcnt and a thousand waves on one address serialise in L2
-#define DC_STAMP_OFF 4768 // past the policy image and its 112 floats of sum scratch AND past the network's activations, which share the scratch in mega_dc.hip.h
+#define DC_STAMP_OFF 5136 // past the policy image and its 112 floats of sum scratch AND past the network's activations, which share the scratch in mega_dc.hip.h
 #define DC_LDS_FLOATS (DC_STAMP_OFF + 32)
 #define DST(i, v) do { if (lane == 0) ((unsigned long long *)(lds + DC_STAMP_OFF))[i] += (unsigned long long)(v); } while (0)
 #else
