@@ -1339,9 +1339,6 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
                     const int waves = getenv("BB_QUEUE_WAVES") ? atoi(getenv("BB_QUEUE_WAVES")) : 12;
                     const int nw = getenv("BB_QUEUE_NETW") ? netw : (waves == 12 ? 8 : 5);
 #define QX3(NW, WV) k_selfplay_queue<G, NW, true, WV><<<nb, WV * 64, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim)
-                    if (waves == 16) { // tuning: 128 VGPRs per wave
-                        QX3(8, 16);
-                    } else
                     if (waves == 12) { // 8 network + 4 tree waves of 168 VGPRs (default); BB_QUEUE_WAVES=8: 5 + 3 (6 + 2) waves of 256
                         if (nw == 6) QX3(6, 12);
                         else if (nw == 7) QX3(7, 12);
