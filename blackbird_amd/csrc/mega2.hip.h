@@ -176,6 +176,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
     // pipeline of a workgroup ran empty game by game at the end of every launch and the launch waited for its slowest
     // workgroup (~35 ms of a 16-step launch); a game's results do not depend on when its visits happen.
     __shared__ int wg_pool, wg_dry, wg_refill;
+    // X3: the prior noise of a posted leaf is drawn by its tree wave (20 % slack) before the leaf is queued, not by the network
+    // wave at the end of the evaluation (the busy side): the same Philox trials in the same order, so the same values.
+    __shared__ float s_noise[X3 ? GW * S : 1];
     constexpr int CHUNK = GW * 32;
 #ifdef BB_STAMPS
     __shared__ long long ts_post[GW], ts_done[GW];
@@ -289,6 +292,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
                     int used = __popcll(__ballot(ready && lane == 0));
                     if (l64 == 0) atomicSub(&wg_pool, used);
                 }
+                if constexpr (X3) {
+                    if (noise_on && ready && posted && lane < G::A)
+                        s_noise[li * S + lane] = bb_beta_noise(ndl.seed, d.leaf_game_id[g], (uint32_t)d.leaf_serial[g], (uint32_t)lane, ndl.alpha);
+                }
 #ifdef BB_STAMPS
                 if (ready && lane == 0 && posted) ts_post[li] = wall_clock64();
 #endif
@@ -349,7 +356,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
 #else
             if constexpr (X3)
                 net_body_x3<G, true, (BB_X3_LEAN != 0)>(ndl, x3l, 1, 0, &myslot[wave], (unsigned char *)wl, (const typename G::State *)d.leaf_state, nullptr,
-                                     d.leaf_game_id, d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false);
+                                     d.leaf_game_id, d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false, nullptr,
+                                     noise_on ? s_noise + li * S : nullptr);
             else
                 net_body<G, 1, BB_QUEUE_WMODE>(ndl, 1, 0, &myslot[wave], wl, (const typename G::State *)d.leaf_state, nullptr,
                                                d.leaf_game_id, d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false);

@@ -190,7 +190,8 @@ __device__ __forceinline__ float pooled_sum(float v) { return wave_sum_f32(v); }
 template <class G>
 __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, float R1, int pos, bool live,
                                          const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
-                                         float *logits_out, float *policy_out, int pstride, WideHead *compact) {
+                                         float *logits_out, float *policy_out, int pstride, WideHead *compact,
+                                         const float *noise_ready = nullptr) {
     constexpr int A = G::A, HW = G::H * G::W;
     const int lane = threadIdx.x & 63;
     const float *hp = nd.head;
@@ -286,6 +287,7 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
             const uint32_t gid = game_id ? game_id[live ? pos : 0] : (uint32_t)noise;
             const uint32_t ser = serial ? (uint32_t)serial[live ? pos : 0] : (uint32_t)pos;
             float r = (nd.dbg & 8) ? nd.alpha : -1.0f;
+            if (noise_ready) r = nd.alpha; // (the draws were made by the caller: persistent kernel, tree waves; see below)
             for (uint32_t k = 0; k < 32 && __any(drawing && r < 0.0f); k += 2) {
                 float mine = (drawing && r < 0.0f) ? bb_beta_pair(nd.seed, gid, ser, (uint32_t)q, ia, ib, k + sub) : -1.0f;
                 float other = dpp_f32(mine, 0); // the pair's other lane (quad permute, no LDS round trip)
@@ -293,7 +295,8 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
                 if (r < 0.0f) r = first >= 0.0f ? first : second;
             }
             r = r >= 0.0f ? r : nd.alpha;
-            const float nz = __shfl(r, 2 * (act ? lane : 0), 64); // action a's draw sits on lane 2a
+            float nz = __shfl(r, 2 * (act ? lane : 0), 64); // action a's draw sits on lane 2a
+            if (noise_ready) nz = act ? noise_ready[lane] : 0.f; // the same draws (bb_beta_noise: same trials in the same order), made ahead
             pr = (1.0f - nd.eps) * pr + nd.eps * (act ? nz : 0.f);
             float t2 = 0.f;
 #pragma unroll

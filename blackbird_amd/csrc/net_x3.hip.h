@@ -116,7 +116,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
                                             unsigned char *wl, const typename G::State *states, const int8_t *planes,
                                             const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
                                             float *logits_out, float *policy_out, int pstride, bool zero_lds,
-                                            WideHead *compact = nullptr) {
+                                            WideHead *compact = nullptr, const float *noise_ready = nullptr) {
     using XG = X3Geom<G>;
     constexpr int W = XG::W, CIN = XG::CIN, HW = XG::HW, NT = XG::NT, SB = XG::SLOT_B;
     constexpr bool WIDE_IN = XG::WIDE_IN;
@@ -612,7 +612,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     }
     NSTAMP(3);
     head_one<G>(nd, pooled_sum(x), pooled_sum(x0), pooled_sum(x1), live ? OI(pos0) : 0, live, game_id, serial, noise, value_out,
-                logits_out, policy_out, pstride, compact);
+                logits_out, policy_out, pstride, compact, noise_ready);
     NSTAMP(4);
 }
 
