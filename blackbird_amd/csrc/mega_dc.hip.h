@@ -53,7 +53,7 @@ __device__ __attribute__((noinline)) void dc_fused_apply(const TreeDev &d_, cons
 }
 // The same on the bf16 matrix pipe (net_x3.hip.h): every operand plane of the tower streams from L2 a layer ahead (this
 // kernel's LDS holds the four waves' scratch and the 4032-wide head).
-__device__ __attribute__((noinline)) void dc_fused_net_x3(const NetDev &nd_, const NetX3 &x3_, const TreeDev &d_, const int *slot, float *nl,
+__device__ __forceinline__ void dc_fused_net_x3(const NetDev &nd_, const NetX3 &x3_, const TreeDev &d_, const int *slot, float *nl,
                                                           DCHeadLocal *hl) {
     const NetDev &nd = *as_lds(&nd_);
     const NetX3 &x3 = *as_lds(&x3_);

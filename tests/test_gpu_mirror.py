@@ -280,7 +280,9 @@ def test_generate_training_samples_dragonchess(tmp_path, monkeypatch):
         board = np.frombuffer(f["boardEncoding"], dtype=np.int8)
         assert pi.shape == (4032,) and board.shape == (8 * 8 * 17,)
         if pi.any():
-            assert abs(pi.sum() - 1.0) < 1e-12 and (pi >= 0).all() and np.count_nonzero(pi) <= 6
+            # visited children: at most playLimit new ones on top of those the re-used subtree brought along (its root had at
+            # most playLimit - 1 visits in the previous search, the first of which expanded it)
+            assert abs(pi.sum() - 1.0) < 1e-12 and (pi >= 0).all() and np.count_nonzero(pi) <= 2 * 6 - 2
         else:
             n_term += 1
     assert n_term == 3  # one terminal example (pi = 0) per game
