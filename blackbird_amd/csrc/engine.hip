@@ -417,7 +417,7 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     d.node_cap = (int)node_capacity_of(cfg);
     d.example_bytes = e->info.example_bytes;
     d.gpw = 64 / e->info.S;
-    d.level_budget = 16; // measured optimum 14-20 on MI355X, Connect4 @800 sims (profiles/README.md)
+    d.level_budget = 12; // tree levels per call; measured 10 / 12 / 16 / 20 / 24 -> 155.6 / 155.8 / 153.6 / 151.6 / 151.2 M sims/s (Connect4 @800, bf16-pipe network)
     d.slot_offset = 0;
     d.pool_g0 = 0;
     d.noise_alpha = cfg->alpha;
