@@ -689,7 +689,7 @@ static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slo
         const size_t pos_floats = (size_t)g.NCB * 4 * GG::PLANE;
         g.inp += (size_t)buf_offset * GG::SLOTS * GG::CP;
         g.act[0] += (size_t)buf_offset * pos_floats;
-        g.act[1] += (size_t)buf_offset * pos_floats;
+        if (g.act[1]) g.act[1] += (size_t)buf_offset * pos_floats; // (not allocated when the tower layers run in the split-operand form)
     }
     k_gnet_input<G><<<nblk((size_t)n_max * GG::HW), 256, 0, st>>>(g, n_max, n_ptr, slot_list, states, planes);
     if (e->gx3.wt) { // tower layers on the bf16 matrix pipe (gnet_x3.hip.h); first conv in float32 MFMA, writing the split form

@@ -18,6 +18,7 @@ def _check(orc, game, F, R, n, seed, perturb=True):
     flat = W.flatten(W.init_weights(gi.C, F, R, 16, gi.A, seed=seed, perturb=perturb))
     eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)
     eng.load_weights(flat)
+    assert eng.net_form() == (1 if os.environ.get("BB_NET_X3") == "0" or R == 0 else 3)
     rng = np.random.RandomState(n + F)
     b, pl = boards_for(game, rng, n)
     st = _lib.pack_grid(game, b, pl)

@@ -33,6 +33,7 @@ def test_net_vs_oracle(orc, monkeypatch, game, og, perturb, n, x3):
     flat = W.flatten(w)
     eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)
     eng.load_weights(flat)
+    assert eng.net_form() == (2 if x3 == "1" else 0)
     rng = np.random.RandomState(n)
     b, pl = boards_for(game, rng, n)
     st = _lib.pack_grid(game, b, pl)
