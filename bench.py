@@ -4,15 +4,17 @@
 Workloads (--workload):
   c2 (default, the headline; BASELINE configs[1]): Connect4 7x6, 800 simulations/move, 4096 concurrent self-play games
      per GPU, network R4/F16/D16 random-init (weight seed 0), c_puct 0.85, temp 1, Beta prior noise alpha 0.2 / eps 0.3
-     (always on in the reference, NetworkFactory.py:176-180), float32.
+     (always on in the reference, NetworkFactory.py:176-180), float32 results (by default formed on the bf16 matrix pipe
+     from exactly split float32 operands, blackbird_amd/csrc/net_x3.hip.h; BB_NET_X3=0: float32 MFMA; `roofline.peak` is
+     the ceiling of the form that ran).
   c5 (configs[4] on one GPU): the same game with the 20-block x 256-filter network (one step is 3.3 M evaluations of
      1.98 GFLOP: use --steps 1 --warmup 0 --prefill 1).
   dc (configs[3]): DragonChess, 400 simulations/move, 1024 concurrent games, R4/F16/D16 on 17 planes, 4032-wide policy
      head, ply cap 512 (the reference has no draw rule: documented deviation).
 
-A "step" is `sims` tree visits of every concurrent game -- one launch-unit of the persistent self-play kernel (or `sims`
-x (tree kernel + network kernel) + one move kernel in the launch-per-round modes).  A visit completes at least one
-simulation (more when it meets terminal leaves whose value is already known), so a step is at least one ply of every
+A "step" is `sims` tree visits per concurrent game, handed out by the persistent self-play kernel from one pool per launch
+(or `sims` x (tree kernel + network kernel) + one move kernel in the launch-per-round modes).  A visit completes at least
+one simulation (more when it meets terminal leaves whose value is already known), so a step is about one ply of every
 game; `plies_per_step` says how many it was.  Finished games hand their slot to a fresh game, so the batch stays full;
 `value` is games completed inside the timed region / wall time (whole job, all ranks).  The timed region = the K steps +
 the extraction to the host of the example records of as many finished games as it produced (SURVEY.md 8d counts example
