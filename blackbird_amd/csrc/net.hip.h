@@ -203,7 +203,9 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
     const float sdv = lane < D ? fmaxf(__builtin_fmaf(R, d1k[lane], (float)HW * d1b[lane]), 0.f) : 0.f;
     float e = d2b[0];
     for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(lane_f(sdv, dd), d2k[dd], e);
-    const float value = tanhf(e);
+    // tanh on the hardware exponential: 1 - 2 / (exp(2e) + 1) (v_exp_f32, v_rcp_f32: absolute error ~1e-7, the library tanhf is
+    // ~60 instructions on the network wave's critical tail); saturates to +-1 through exp's overflow / underflow
+    const float value = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(e * 2.88539008177792681472f) + 1.0f);
     if (live && lane == 0 && value_out) value_out[pos] = value;
     if constexpr (A > 64) {
         // wide policy (DragonChess, A = 4032): see the helpers above
@@ -274,7 +276,7 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
         float m = -INFINITY;
 #pragma unroll
         for (int a = 0; a < A; a++) m = fmaxf(m, lane_f(l, a));
-        float pr = act ? expf(l - m) : 0.f;
+        float pr = act ? wide_expterm(l, m) : 0.f; // exp(l - m) on v_exp_f32, as the wide head does
         float tot = 0.f;
 #pragma unroll
         for (int a = 0; a < A; a++) tot += lane_f(pr, a);

@@ -81,7 +81,6 @@ __device__ __forceinline__ unsigned bf16_bits(float v) { // round to nearest eve
 __device__ __forceinline__ void x3_mfma_switch() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15");
-    asm volatile("s_nop 15");
     __builtin_amdgcn_sched_barrier(0);
 }
 
