@@ -17,14 +17,18 @@
 // search is compared on the evaluations the engine itself produced (bb_net_eval_keyed, tests/test_gpu_noise_parity.py).
 //
 // Layout (one wave = one position, its activations never leave LDS):
-//   X    [slot][plane 0..2][16 ch] bf16 (+ 16 B pad: 112 B per pixel slot, bank-conflict-free; zero halo as in net.hip.h); the three planes of a pixel's 8
-//        channels are one ds_read_b128 each; written in place (a layer's reads are complete before its epilogue starts,
-//        the block input for the skip connection stays in registers)
+//   X    [slot][plane 0..2][16 ch] bf16 + 16 B pad = 112 B per pixel slot (zero halo as in net.hip.h); the three planes of a
+//        pixel's 8 channels are one ds_read_b128 each; an MFMA tile is whole board rows (X3Geom::PPT), which together with
+//        the 112-byte stride makes those reads bank-conflict-free; written in place (a layer's reads are complete before
+//        its epilogue starts, the block input for the skip connection stays in registers) -- or into a second buffer (PP)
 //   inp  [slot][4 ch] bf16: the input planes (small integers: exact in bf16, no split)
 //   the last layer leaves float32 [slot][16 ch] in the first 64 B of each interior slot for the heads.
 //   K order of a tower layer: taps (0,1), (3,4), (6,7), (2,5) as four K = 32 slices (lane group g = lane >> 4 holds
 //   channels 8 (g & 1) .. +7 of the slice's tap g >> 1), then tap 8 as one K = 16 slice (v_mfma_f32_16x16x16_bf16).
-//   Weights: pre-split and pre-swizzled on the host into the A-operand lane order (engine.hip: pack_x3).
+//   Weights: pre-split and pre-swizzled on the host into the A-operand lane order (engine.hip: pack_x3); planes 1 and 2 may
+//   live in the caller's LDS, plane 3 always streams from L2 a layer ahead.
+//   Callers: k_net_x3 (bb_net_eval, lock-step and asynchronous-round search), k_selfplay_queue (mega2.hip.h),
+//   k_dc_selfplay_fused (mega_dc.hip.h); the per-layer launches of wider networks use the same split in gnet_x3.hip.h.
 #pragma once
 #include "net.hip.h"
 
