@@ -7,7 +7,7 @@
 //    first conv (float32 MFMA on the exact int8 planes, gnet.hip.h) writes that form, the last tower layer writes the
 //    float32 layout the heads kernel reads;
 //  * K order per output: channel blocks ascending, inside a block the slices taps (0,1), (3,4), (6,7), (2,5); then tap 8 of
-//    every channel block as K = 16 slices (the two MFMA kinds are never interleaved: net_x3.hip.h x3_mfma_switch).  The
+//    every channel block as K = 16 slices (zero-extended to the K = 32 instruction: net_x3.hip.h x3_k16).  The
 //    order does not depend on the tiling, so the throughput launch (PPB positions x 4 filter blocks per wave) and the
 //    latency launch (1 x 1) give the same bits;
 //  * a wave = FBW filter blocks x NT pixel tiles; the B operand (activations) is shared by its filter blocks and, through
@@ -143,7 +143,6 @@ __global__ void __launch_bounds__(256) k_gnet_conv_x3(GNetDev gd, GNetX3 gx, int
         slice(wb, wa, p1, p0, u + 1);
     }
     // ---- tap 8 of every channel block: K = 16 ------------------------------------------------------------------------------
-    x3_mfma_switch();
     constexpr int T8 = (2 * (W + 1) + 2) * SB;
     for (int cb = 0; cb < NCB; cb++) {
         s16x4 w8[FBW][3], y[NT][3];
@@ -159,7 +158,7 @@ __global__ void __launch_bounds__(256) k_gnet_conv_x3(GNetDev gd, GNetX3 gx, int
 #pragma unroll
             for (int t = 0; t < NT; t++)
 #pragma unroll
-                for (int f = 0; f < FBW; f++) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w8[f][qw], y[t][qx], acc[f][t], 0, 0, 0);
+                for (int f = 0; f < FBW; f++) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(w8[f][qw]), x3_k16(y[t][qx]), acc[f][t], 0, 0, 0);
         };
         m8(2, 0);
         m8(1, 1);
@@ -168,7 +167,6 @@ __global__ void __launch_bounds__(256) k_gnet_conv_x3(GNetDev gd, GNetX3 gx, int
         m8(0, 1);
         m8(0, 0);
     }
-    x3_mfma_switch();
     // ---- epilogue ----------------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int f = 0; f < FBW; f++) {

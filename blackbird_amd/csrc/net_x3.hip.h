@@ -24,7 +24,7 @@
 //   inp  [slot][4 ch] bf16: the input planes (small integers: exact in bf16, no split)
 //   the last layer leaves float32 [slot][16 ch] in the first 64 B of each interior slot for the heads.
 //   K order of a tower layer: taps (0,1), (3,4), (6,7), (2,5) as four K = 32 slices (lane group g = lane >> 4 holds
-//   channels 8 (g & 1) .. +7 of the slice's tap g >> 1), then tap 8 as one K = 16 slice (v_mfma_f32_16x16x16_bf16).
+//   channels 8 (g & 1) .. +7 of the slice's tap g >> 1), then tap 8 as one K = 16 slice (zero-extended: x3_k16).
 //   Weights: pre-split and pre-swizzled on the host into the A-operand lane order (engine.hip: pack_x3); planes 1 and 2 may
 //   live in the caller's LDS, plane 3 always streams from L2 a layer ahead.
 //   Callers: k_net_x3 (bb_net_eval, lock-step and asynchronous-round search), k_selfplay_queue (mega2.hip.h),
@@ -78,14 +78,16 @@ __device__ __forceinline__ unsigned bf16_bits(float v) { // round to nearest eve
     return (unsigned)__builtin_bit_cast(unsigned short, h);
 }
 
-// Between a K = 32 and a K = 16 MFMA that accumulate into the same registers.  Measured on gfx950 / ROCm 7.2: with the two
-// opcodes back to back (v_mfma_f32_16x16x32_bf16 -> v_mfma_f32_16x16x16_bf16 on the same accumulator, nothing in between)
-// the second one read its SrcC before the first had written it and that MFMA's contribution was lost -- the compiler
-// inserts no wait states there.  So the two kinds are never interleaved, and every switch waits explicitly.
-__device__ __forceinline__ void x3_mfma_switch() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 15");
-    __builtin_amdgcn_sched_barrier(0);
+// The 9th tap has only 16 channels of K.  v_mfma_f32_16x16x16_bf16 costs the same 17 cycles as the K = 32 instruction on
+// gfx950 (tools/micro/mfma_rate.hip), and mixing the two on one accumulator needs care: with K = 32 directly followed by
+// K = 16 on the same registers (ROCm 7.2) the second read its SrcC before the first had written it and a whole MFMA's
+// contribution was lost -- no wait states are inserted (tests/test_gpu_net.py: ..._every_tap_and_plane_contributes).  So a
+// K = 16 operand (4 bf16 per lane: channels 4g .. 4g + 3) is zero-extended to the K = 32 form (the upper four k slots of
+// every lane group multiply zero by zero) and the tower uses one MFMA kind throughout.
+__device__ __forceinline__ bf16x8 x3_k16(s16x4 v) {
+    const u32x2 lo = __builtin_bit_cast(u32x2, v);
+    const u32x4 both = {lo[0], lo[1], 0u, 0u};
+    return __builtin_bit_cast(bf16x8, both);
 }
 
 // y[0..3] -> three bf16 planes, each packed as 2 dwords (4 x bf16)
@@ -254,12 +256,10 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
         for (int q = 2; q >= 0; q--) // small terms first
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[q], b[t], acc[t], 0, 0, 0);
-        x3_mfma_switch();
 #pragma unroll
         for (int q = 2; q >= 0; q--)
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w0b[q], b8[t], acc[t], 0, 0, 0);
-        x3_mfma_switch();
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(w0b[q]), x3_k16(b8[t]), acc[t], 0, 0, 0);
         }
 #pragma unroll
         for (int t = 0; t < NT; t++) {
@@ -348,17 +348,15 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             }
             const s16x4 w38 = w3c8;
             if (l + 1 < L) request_layer(l + 1);
-            x3_mfma_switch();
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w38, ya[t], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vb, yb[t], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, yc[t], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vb, ya[t], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, yb[t], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, ya[t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(w38), x3_k16(ya[t]), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(vb), x3_k16(yb[t]), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(va), x3_k16(yc[t]), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(vb), x3_k16(ya[t]), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(va), x3_k16(yb[t]), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(va), x3_k16(ya[t]), acc[t], 0, 0, 0);
             }
-            x3_mfma_switch();
         } else {
         bf16x8 wc[2], wn[2], x0[NT], x1[NT], x2[NT];
         s16x4 w8[2], y0[NT], y1[NT], y2[NT];
@@ -420,20 +418,18 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
         }
         const s16x4 w38 = w3c8;
         if (l + 1 < L) request_layer(l + 1); // (this layer's slice registers were read for the last time above; w8 / w38 are copies)
-        x3_mfma_switch();
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w38, y0[t], acc[t], 0, 0, 0);
-#pragma unroll
-        for (int q = 1; q >= 0; q--)
-#pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w8[q], y0[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(w38), x3_k16(y0[t]), acc[t], 0, 0, 0);
 #pragma unroll
         for (int q = 1; q >= 0; q--)
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w8[q], y1[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(w8[q]), x3_k16(y0[t]), acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w8[0], y2[t], acc[t], 0, 0, 0);
-        x3_mfma_switch();
+        for (int q = 1; q >= 0; q--)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(w8[q]), x3_k16(y1[t]), acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(w8[0]), x3_k16(y2[t]), acc[t], 0, 0, 0);
         }
         // (the batch-norm constants are read here, not at the top of the layer: 8 registers less through the slices)
         const f32x4 scale = *(const f32x4 *)(ep + 16 + 4 * g), shift = *(const f32x4 *)(ep + 32 + 4 * g);

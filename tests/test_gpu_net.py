@@ -207,7 +207,7 @@ def test_split_operand_tower_every_tap_and_plane_contributes(game):
     has one bit in each plane; placed on one tap of the first conv (a network without residual blocks, identity batch norm) the
     value head sees it only if that tap's slice carried all three planes.  The first version lost plane 2 of every K = 32 slice:
     a K = 32 MFMA directly followed by a K = 16 MFMA on the same accumulator reads its SrcC too early on gfx950 / ROCm 7.2
-    (x3_mfma_switch).  Checked through the public outputs: the value of an empty board equals the float64 statement within
+    (the tower uses one MFMA kind now: net_x3.hip.h x3_k16).  Checked through the public outputs: the value of an empty board equals the float64 statement within
     1e-6 only when nothing is lost (a lost plane 2 costs 1e-3)."""
     gi = _lib.game_info(game)
     H, Wd, _ = _lib.GRID[game]
