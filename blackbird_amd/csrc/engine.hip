@@ -417,7 +417,7 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     d.node_cap = (int)node_capacity_of(cfg);
     d.example_bytes = e->info.example_bytes;
     d.gpw = 64 / e->info.S;
-    d.level_budget = 12; // tree levels per call; measured 10 / 12 / 16 / 20 / 24 -> 155.6 / 155.8 / 153.6 / 151.6 / 151.2 M sims/s (Connect4 @800, bf16-pipe network)
+    d.level_budget = 16; // tree levels per call of the launch-per-round structures (20 x 256 in-search: 12 / 16 / 24 -> 93 / 105 / 106 k evaluations/s); the persistent kernel uses 12, below
     d.slot_offset = 0;
     d.pool_g0 = 0;
     d.noise_alpha = cfg->alpha;
@@ -1331,6 +1331,8 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
             bool timed = e->time_every > 0 && e->ev_used + 2 <= e->ev_pool.size();
             if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
             TreeDev dm = d;
+            // tree levels per call: 10 / 12 / 16 / 20 / 24 -> 155.6 / 155.8 / 153.6 / 151.6 / 151.2 M sims/s (Connect4 @800, bf16-pipe network)
+            if (!getenv("BB_LEVEL_BUDGET")) dm.level_budget = 12;
             k_set_i32<<<1, 1, 0, e->stream>>>(d.visit_pool, d.n_slots * rounds); // the launch's pool of visits (mega2.hip.h)
             const int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
             const int netw = getenv("BB_QUEUE_NETW") ? atoi(getenv("BB_QUEUE_NETW")) : 8; // network waves of the 12 (tuning)
