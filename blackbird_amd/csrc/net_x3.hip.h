@@ -21,7 +21,8 @@
 //        pixel's 8 channels are one ds_read_b128 each; an MFMA tile is whole board rows (X3Geom::PPT), which together with
 //        the 112-byte stride makes those reads bank-conflict-free; written in place (a layer's reads are complete before
 //        its epilogue starts, the block input for the skip connection stays in registers) -- or into a second buffer (PP)
-//   inp  [slot][4 ch] bf16: the input planes (small integers: exact in bf16, no split)
+//   the input planes (small integers: exact in bf16, no split) sit in their pixel's slot: 4 planes in the 16-byte pad,
+//   DragonChess' 17 in the first 64 B (the first conv's outputs overwrite them after its reads)
 //   the last layer leaves float32 [slot][16 ch] in the first 64 B of each interior slot for the heads.
 //   K order of a tower layer: taps (0,1), (3,4), (6,7), (2,5) as four K = 32 slices (lane group g = lane >> 4 holds
 //   channels 8 (g & 1) .. +7 of the slice's tap g >> 1), then tap 8 as one K = 16 slice (zero-extended: x3_k16).
@@ -53,7 +54,8 @@ struct X3Geom {
     // 8: every ds_read_b128 of a pixel plane is a 2-way bank conflict), at 112 B they start 28 banks apart (period 16: none)
     static constexpr int SLOT_B = 112;
     static constexpr int X_B = SLOTS * SLOT_B;
-    static constexpr int INP_B = WIDE_IN ? 0 : (SLOTS * 8 + 15) / 16 * 16; // wide inputs ([32 ch] bf16 = 64 B) sit in their X slot
+    static constexpr int INP_B = 0; // the input planes sit in their own X slot: wide ([32 ch] bf16) in its first 64 B, narrow ([4 ch]) in the pad
+    static constexpr int INP_OFF = WIDE_IN ? 0 : 96;
     static constexpr int STATE_B = ((int)sizeof(typename G::State) + 15) / 16 * 16;
     static constexpr int WAVE_BYTES = X_B + INP_B + STATE_B;
     static constexpr int WAVE_BYTES_PP = 2 * X_B + INP_B + STATE_B; // two activation buffers (net_body_x3 PP: DragonChess kernel)
@@ -130,7 +132,6 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     static_assert(!PP || !WLDS, "the two-buffer form keeps its weights in registers, a layer ahead");
     unsigned char *X = wl;
     unsigned char *X2 = wl + XG::X_B; // (PP only)
-    unsigned char *inp = wl + (PP ? 2 : 1) * XG::X_B;
     typename G::State *sst = (typename G::State *)(wl + (PP ? 2 : 1) * XG::X_B + XG::INP_B);
     auto OI = [&](int pos) { return slot_list ? slot_list[pos] : pos; };
     const bool live = pos0 < n;
@@ -203,14 +204,14 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
         unsigned b[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) b[c] = __float_as_uint((float)v[c]) >> 16;
-        *(u32x2 *)(inp + ((y + 1) * (W + 1) + (x + 1)) * 8) = u32x2{b[0] | (b[1] << 16), b[2] | (b[3] << 16)};
+        *(u32x2 *)(X + ((y + 1) * (W + 1) + (x + 1)) * SB + XG::INP_OFF) = u32x2{b[0] | (b[1] << 16), b[2] | (b[3] << 16)};
     }
     // ---- per-tile addressing (bytes).  Offsets are biased by the window's top-left tap (TAP0 slots), so every tap is a
     // non-negative immediate; MFMA columns past the last pixel repeat the last pixel (same values to the same addresses).
     constexpr int TAP0 = (W + 1) + 1;
     int aA[NT], aB[NT], aC[NT], aO[NT], iA[NT];
     auto tapoff = [](int tap) { return (tap / 3) * (W + 1) + (tap % 3); };
-    const int t0off = tapoff(2 * g) * 8, t1off = tapoff(2 * g + 1) * 8; // first conv: lane group g holds taps 2g, 2g + 1
+    const int t0off = tapoff(2 * g) * SB, t1off = tapoff(2 * g + 1) * SB; // first conv: lane group g holds taps 2g, 2g + 1
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         int q = t * XG::PPT + (nn < XG::PPT ? nn : XG::PPT - 1);
@@ -221,7 +222,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
         aB[t] = base * SB + gh * (W + 1) * SB + gl * 16;   // slice (2, 5): + 2 SB
         aC[t] = base * SB + g * 8;                          // tap 8 (K = 16: channels 4g .. 4g + 3): + (2 (W + 1) + 2) SB
         aO[t] = (base + TAP0) * SB + g * 8;                 // this lane's 4 output channels of its pixel, plane 0
-        iA[t] = base * 8;
+        iA[t] = base * SB + XG::INP_OFF;
     }
     wave_lds_handover();
     NSTAMP(0);
@@ -247,10 +248,10 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
         s16x4 b8[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            u32x2 lo = *(const u32x2 *)(inp + iA[t] + t0off), hi = *(const u32x2 *)(inp + iA[t] + t1off);
+            u32x2 lo = *(const u32x2 *)(X + iA[t] + t0off), hi = *(const u32x2 *)(X + iA[t] + t1off);
             u32x4 both = {lo[0], lo[1], hi[0], hi[1]};
             b[t] = __builtin_bit_cast(bf16x8, both);
-            b8[t] = __builtin_bit_cast(s16x4, *(const u32x2 *)(inp + iA[t] + tapoff(8) * 8));
+            b8[t] = __builtin_bit_cast(s16x4, *(const u32x2 *)(X + iA[t] + tapoff(8) * SB));
         }
 #pragma unroll
         for (int q = 2; q >= 0; q--) // small terms first
