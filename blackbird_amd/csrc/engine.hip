@@ -747,17 +747,21 @@ static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slo
     return BB_OK;
 }
 
-// w0:   [plane][lane][8] (taps 2g, 2g + 1 x 4 input planes) then [plane][lane][4] (tap 8, lane group 0 only)
+// w0:   narrow input: [plane][lane][8] (taps 2g, 2g + 1 x 4 input planes), then ONE operand [lane][8] for tap 8: lane group 0
+//       = [w1 | w2] (4 input planes each), group 1 = [w3 | 0], groups 2, 3 zero -- against B = [x | x] that is all three planes
+//       of the tap in one K = 32 product.  Wide input (DragonChess): [tap][plane][lane][8], lane group g = input planes 8g .. 8g + 7
 // wt12: per layer [slice 0..3][plane 0..1][lane][8] (slices = taps (0,1), (3,4), (6,7), (2,5); lane group g: tap g >> 1 of the
-//       slice, channels 8 (g & 1) .. + 7) then [plane 0..1][lane][4] (tap 8, channels 4g .. 4g + 3)
-// wt3:  per layer [slice][lane][8] then [lane][4]: the third plane alone
-// wt8:  per layer [plane][lane][8]: tap 8 as a K = 32 slice, lane groups 0, 1 = channels 0..7, 8..15, groups 2, 3 zero
+//       slice, channels 8 (g & 1) .. + 7) then tap 8: [plane 0..1][channel half][filter][8] (what both halves of the lane groups read)
+// wt3:  per layer [slice][lane][8] (the third plane alone) then [lane][8] = tap 8's operand [w1 | w3]: lane groups 0, 1 plane 1,
+//       groups 2, 3 plane 3, channels 8 (g & 1) .. + 7
+// wt8:  per layer [3][lane][8]: tap 8's three A operands [w1|w1], [w2|w2], [w1|w3] as 64-lane images (PP form)
+// (tap 8 = three K = 32 products on plane-concatenated operands: [w1|w1].[x1;x2] + [w2|w2].[x1;x2] + [w1|w3].[x3;x1], net_x3.hip.h)
 static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vector<uint16_t> &wt12, std::vector<uint16_t> &wt3,
                     std::vector<uint16_t> &wt8) {
     const int F = 16, C = w->C, R = w->R;
     const bool wide = C > 4; // DragonChess: one K = 32 slice per tap, lane group g = input planes 8g .. 8g + 7
-    w0.assign(wide ? (size_t)9 * 3 * 64 * 8 : (size_t)(3 * 64 * 8 + 3 * 64 * 4), 0);
-    const size_t per12 = 4 * 2 * 64 * 8 + 2 * 64 * 4, per3 = 4 * 64 * 8 + 64 * 4;
+    w0.assign(wide ? (size_t)9 * 3 * 64 * 8 : (size_t)(3 * 64 * 8 + 64 * 8), 0);
+    const size_t per12 = 4 * 2 * 64 * 8 + 2 * 32 * 8, per3 = 4 * 64 * 8 + 64 * 8;
     wt12.assign((size_t)2 * R * per12, 0);
     wt3.assign((size_t)2 * R * per3, 0);
     wt8.assign((size_t)2 * R * 3 * 64 * 8, 0);
@@ -778,9 +782,11 @@ static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vec
             bf16_split3(ch < C ? w->conv0_k[((size_t)tap * C + ch) * F + f] : 0.f, h);
             for (int q = 0; q < 3; q++) w0[((size_t)q * 64 + lane) * 8 + i] = h[q];
         }
-        for (int i = 0; i < 4; i++) {
-            bf16_split3((g == 0 && i < C) ? w->conv0_k[((size_t)8 * C + i) * F + f] : 0.f, h);
-            for (int q = 0; q < 3; q++) w0[(size_t)3 * 64 * 8 + ((size_t)q * 64 + lane) * 4 + i] = h[q];
+        for (int i = 0; i < 8 && g < 2; i++) { // tap 8: k slot i of lane group g = plane 2g + (i >> 2) of input plane i & 3
+            const int q = 2 * g + (i >> 2), ch = i & 3;
+            if (q > 2) continue;
+            bf16_split3(ch < C ? w->conv0_k[((size_t)8 * C + ch) * F + f] : 0.f, h);
+            w0[(size_t)3 * 64 * 8 + (size_t)lane * 8 + i] = h[q];
         }
     }
     static const int slice_taps[4][2] = {{0, 1}, {3, 4}, {6, 7}, {2, 5}};
@@ -795,14 +801,15 @@ static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vec
                     for (int q = 0; q < 2; q++) o12[(((size_t)sl * 2 + q) * 64 + lane) * 8 + i] = h[q];
                     o3[((size_t)sl * 64 + lane) * 8 + i] = h[2];
                 }
-            for (int i = 0; i < 4; i++) {
-                bf16_split3(w->blk_k[(((size_t)l * 9 + 8) * F + (4 * g + i)) * F + f], h);
-                for (int q = 0; q < 2; q++) o12[(size_t)4 * 2 * 64 * 8 + ((size_t)q * 64 + lane) * 4 + i] = h[q];
-                o3[(size_t)4 * 64 * 8 + (size_t)lane * 4 + i] = h[2];
-            }
-            for (int i = 0; i < 8 && g < 2; i++) {
-                bf16_split3(w->blk_k[(((size_t)l * 9 + 8) * F + (8 * g + i)) * F + f], h);
-                for (int q = 0; q < 3; q++) wt8[(((size_t)l * 3 + q) * 64 + lane) * 8 + i] = h[q];
+            for (int i = 0; i < 8; i++) { // tap 8, channels 8 (g & 1) .. + 7
+                bf16_split3(w->blk_k[(((size_t)l * 9 + 8) * F + (8 * (g & 1) + i)) * F + f], h);
+                if (g < 2)
+                    for (int q = 0; q < 2; q++) o12[(size_t)4 * 2 * 64 * 8 + (((size_t)q * 2 + g) * 16 + f) * 8 + i] = h[q];
+                const uint16_t a3 = g < 2 ? h[0] : h[2];
+                o3[(size_t)4 * 64 * 8 + (size_t)lane * 8 + i] = a3;
+                wt8[(((size_t)l * 3 + 0) * 64 + lane) * 8 + i] = h[0];
+                wt8[(((size_t)l * 3 + 1) * 64 + lane) * 8 + i] = h[1];
+                wt8[(((size_t)l * 3 + 2) * 64 + lane) * 8 + i] = a3;
             }
         }
     }

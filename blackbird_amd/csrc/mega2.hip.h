@@ -33,6 +33,9 @@
 #ifndef BB_NET_APPLIES
 #define BB_NET_APPLIES -1 // tuning override of NET_APPLIES (k_selfplay_queue): 1 network waves apply their result, 0 tree waves do
 #endif
+#ifndef BB_TREE_HEADS
+#define BB_TREE_HEADS 1 // bf16-pipe network: 1 = the value / policy tails of an evaluation run on the tree wave that picks it up (net.hip.h head_tree)
+#endif
 #ifndef BB_X3_LEAN
 #define BB_X3_LEAN 0 // net_x3.hip.h operand schedule of the persistent kernel: 0 = a phase ahead (38 spilled registers at 168, still faster), 1 = in place
 #endif
@@ -134,15 +137,19 @@ __device__ __attribute__((noinline)) int queue_pop(QueueCtl *c, long long t_star
 
 // Tree-wave side: publish this call's outcome for every game leader lane (`leader`) of the wave.  Not inlined for the
 // same reason as queue_pop: the lanes of the wave must come back from here together.
-__device__ __attribute__((noinline)) void queue_push(QueueCtl *c, int *state_word, bool leader, bool posted, int li) {
-    release_global_then_lds(); // mailbox + tree writes before the queue entry
+// GLOBAL_TOO: the consumer of the queue entry also reads what this wave wrote to global memory (the network wave applies
+// the result to the tree itself: float32 form); otherwise only the mailbox in LDS has to be visible.
+template <bool GLOBAL_TOO>
+__device__ __attribute__((noinline)) void queue_push(QueueCtl *c, uint8_t *state_byte, bool leader, bool posted, int li) {
+    if (GLOBAL_TOO) release_global_then_lds(); // mailbox + tree writes before the queue entry
+    else __threadfence_block();
     if (leader) {
         if (posted) {
-            *(volatile int *)state_word = 1;
+            *(volatile uint8_t *)state_byte = 1;
             int idx = atomicAdd(&c->tail, 1); // the entry becomes valid when its slot turns non-negative
             *(volatile int *)&c->q[idx & (MEGA2_QCAP - 1)] = li;
         } else {
-            *(volatile int *)state_word = 0;
+            *(volatile uint8_t *)state_byte = 0;
         }
     }
 }
@@ -169,7 +176,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
     __shared__ __attribute__((aligned(16))) float wlds[WT_F + W0_F + EPI_F + HEAD_F];
     __shared__ QueueCtl qc;
     __shared__ GameShadow<G, GW> shadow;
-    __shared__ int gstate[GW];      // 0 owned by its tree wave, 1 leaf queued / being evaluated, 2 result published
+    // Per-game state: 0 owned by its tree wave, 1 leaf queued / being evaluated, 2 result published.  One byte per game, the
+    // games of a tree wave next to each other (GSI): the wave sees all of its games' states in ONE 8-byte LDS read.
+    static_assert(GPT <= 8, "a tree wave's game states are one 8-byte word");
+    __shared__ __attribute__((aligned(8))) uint8_t gstate[TREEW * 8];
+#define GSI(li) ((((li) % TREEW) << 3) + (li) / TREEW)
     __shared__ int myslot[NETW];
     // Visits are not dealt per game: the launch has ONE pool (dg.visit_pool = slots x visits) that the workgroups draw from
     // in chunks, and every game of a workgroup keeps searching until the pool is dry.  With a fixed count per game the
@@ -179,6 +190,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
     // X3: the prior noise of a posted leaf is drawn by its tree wave (20 % slack) before the leaf is queued, not by the network
     // wave at the end of the evaluation (the busy side): the same Philox trials in the same order, so the same values.
     __shared__ float s_noise[X3 ? GW * S : 1];
+    constexpr bool TREE_HEADS = X3 && !NET_APPLIES && (BB_TREE_HEADS != 0);
+    __shared__ float s_pooled[TREE_HEADS ? GW * 4 : 1]; // R, R0, R1 of a finished evaluation (the tree wave forms value and priors from them)
     constexpr int CHUNK = GW * 32;
 #ifdef BB_STAMPS
     __shared__ long long ts_post[GW], ts_done[GW];
@@ -197,7 +210,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
         wg_dry = 0;
         wg_refill = 0;
     }
-    if (threadIdx.x < GW) gstate[threadIdx.x] = 0;
+    if (threadIdx.x < TREEW * 8) gstate[threadIdx.x] = 0;
 #ifdef BB_STAMPS_NET
     if (threadIdx.x < 8) s_net_stamps[threadIdx.x] = 0;
 #endif
@@ -236,8 +249,21 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
 #ifdef BB_STAMPS
         long long t_work = 0, t_all0 = clock64(), n_calls = 0, n_lanes = 0, t_pick = 0, n_pick = 0;
 #endif
+        // TREE_HEADS: value + priors of a finished evaluation from the pooled head activations its network wave left in s_pooled
+        auto finish_eval = [&](bool doit) __attribute__((always_inline)) {
+            if (doit) {
+                const float *hp = as_lds(ndl.head);
+                const float nz = (noise_on && lane < G::A) ? s_noise[li * S + lane] : 0.f;
+                float prior;
+                const float value = head_tree<G>(ndl, hp, s_pooled[li * 4], s_pooled[li * 4 + 1], s_pooled[li * 4 + 2], lane, l64 - lane,
+                                                 noise_on != 0, nz, &prior);
+                if (lane == 0) d.eval_value[g] = value;
+                if (lane < G::A) d.eval_policy[g * S + lane] = prior;
+            }
+            wave_lds_handover();
+        };
         for (;;) {
-            int stt = mine ? lds_load(&gstate[li]) : 1;
+            int stt = mine ? (int)*(volatile uint8_t *)&gstate[GSI(li)] : 1;
             const int pool = lds_load(&wg_pool), dry = lds_load(&wg_dry);
             if (pool < CHUNK / 4 && !dry) { // (wave-uniform) top the workgroup's share up before it runs out
                 if (l64 == 0 && atomicCAS(&wg_refill, 0, 1) == 0) {
@@ -256,6 +282,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
             if (__any(ready)) {
                 __threadfence_block(); // acquire: the network wave's results for state 2
                 bool posted = false;
+                if constexpr (TREE_HEADS) finish_eval(ready && stt == 2);
 #ifdef BB_STAMPS
                 long long ts = clock64();
                 n_calls++;
@@ -299,7 +326,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
 #ifdef BB_STAMPS
                 if (ready && lane == 0 && posted) ts_post[li] = wall_clock64();
 #endif
-                queue_push(&qc, &gstate[li < GW ? li : 0], ready && lane == 0, posted, li);
+                queue_push<NET_APPLIES>(&qc, &gstate[GSI(li < GW ? li : 0)], ready && lane == 0, posted, li);
 #ifdef BB_STAMPS
                 t_work += clock64() - ts;
 #endif
@@ -311,6 +338,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
                     break;
                 }
             }
+        }
+        if constexpr (TREE_HEADS) { // an evaluation that nobody picked up any more goes to the next launch through the game's mailbox
+            __threadfence_block();
+            finish_eval(mine && *(volatile uint8_t *)&gstate[GSI(li)] == 2);
         }
         if (l64 == 0) atomicAdd(&qc.tree_done, 1);
 #ifdef BB_STAMPS
@@ -355,9 +386,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
             }
 #else
             if constexpr (X3)
-                net_body_x3<G, true, (BB_X3_LEAN != 0)>(ndl, x3l, 1, 0, &myslot[wave], (unsigned char *)wl, (const typename G::State *)d.leaf_state, nullptr,
+                net_body_x3<G, true, (BB_X3_LEAN != 0), false, TREE_HEADS>(ndl, x3l, 1, 0, &myslot[wave], (unsigned char *)wl, (const typename G::State *)d.leaf_state, nullptr,
                                      d.leaf_game_id, d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false, nullptr,
-                                     noise_on ? s_noise + li * S : nullptr);
+                                     noise_on ? s_noise + li * S : nullptr, TREE_HEADS ? s_pooled + li * 4 : nullptr);
             else
                 net_body<G, 1, BB_QUEUE_WMODE>(ndl, 1, 0, &myslot[wave], wl, (const typename G::State *)d.leaf_state, nullptr,
                                                d.leaf_game_id, d.leaf_serial, noise_on, d.eval_value, nullptr, d.eval_policy, S, false);
@@ -383,7 +414,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
 #ifdef BB_STAMPS
             if (l64 == 0) ts_done[li] = wall_clock64();
 #endif
-            if (l64 == 0) gstate[li] = 2;
+            if (l64 == 0) *(volatile uint8_t *)&gstate[GSI(li)] = 2;
 #ifdef BB_STAMPS
             t_work += clock64() - ts;
 #endif
@@ -406,7 +437,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
         if (threadIdx.x == 0) d.ctr[6] += 1;
         // a leaf that was queued but never evaluated must not be applied by the next launch (its mailbox holds the
         // previous evaluation): drop it, the simulation is redone from the root
-        if ((int)threadIdx.x < n_mine && gstate[threadIdx.x] == 1) shadow.pend_leaf[threadIdx.x] = -1;
+        if ((int)threadIdx.x < n_mine && gstate[GSI(threadIdx.x)] == 1) shadow.pend_leaf[threadIdx.x] = -1;
     }
     __syncthreads();
     shadow.store(dg, g0, n_mine, MEGA2_THREADS); // hand the per-game state back to HBM

@@ -310,6 +310,47 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
     }
 }
 
+// head_one's value / policy tails for a dense game, computed by the S lanes of a tree wave that own the game (persistent
+// kernel: the network wave stops at the pooled activations R, R0, R1 and the tree wave that picks the result up finishes it --
+// the network waves are the busy side).  Same operations in the same order as head_one, so the same bits: every lane forms
+// the value chain redundantly (no cross-lane traffic), action a sits on lane a of the game's lane group, the ordered softmax
+// sums gather their terms with ds_bpermute (`base` = first lane of the group).  `nz` = this lane's prior-noise draw (made
+// ahead by the same tree wave).  Returns the value; *prior_out = this lane's prior (lanes >= A: 0).
+template <class G>
+__device__ __forceinline__ float head_tree(const NetDev &nd, const float *hp, float R, float R0, float R1, int lane, int base, bool noise,
+                                           float nz, float *prior_out) {
+    constexpr int A = G::A, HW = G::H * G::W;
+    const int D = nd.D;
+    const float *d1k = hp + nd.off_d1k, *d1b = hp + nd.off_d1b, *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
+    const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
+    float e = d2b[0];
+    for (int dd = 0; dd < D; dd++) {
+        const float sdv = fmaxf(__builtin_fmaf(R, d1k[dd], (float)HW * d1b[dd]), 0.f);
+        e = __builtin_fmaf(sdv, d2k[dd], e);
+    }
+    const float value = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(e * 2.88539008177792681472f) + 1.0f);
+    const bool act = lane < A;
+    const int la = act ? lane : 0;
+    const float l = act ? wide_logit<HW>(R0, R1, pdk[la], pdk[A + la], pdb[la]) : -INFINITY;
+    float m = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < A; a++) m = fmaxf(m, __shfl(l, base + a, 64));
+    float pr = act ? wide_expterm(l, m) : 0.f;
+    float tot = 0.f;
+#pragma unroll
+    for (int a = 0; a < A; a++) tot += __shfl(pr, base + a, 64);
+    pr = pr / tot;
+    if (noise) {
+        pr = (1.0f - nd.eps) * pr + nd.eps * (act ? nz : 0.f);
+        float t2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < A; a++) t2 += __shfl(pr, base + a, 64);
+        pr = pr / t2;
+    }
+    *prior_out = act ? pr : 0.f;
+    return value;
+}
+
 // The same for PW positions whose per-pixel head activations sit in memory (LDS): rv[PW*HW], rp[PW*HW][2].
 template <class G, int PW>
 __device__ __forceinline__ void net_head_tail(const NetDev &nd, int n, int pos0, const int *slot_list, const float *rv,

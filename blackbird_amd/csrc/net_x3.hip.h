@@ -17,15 +17,30 @@
 // search is compared on the evaluations the engine itself produced (bb_net_eval_keyed, tests/test_gpu_noise_parity.py).
 //
 // Layout (one wave = one position, its activations never leave LDS):
-//   X    [slot][plane 0..2][16 ch] bf16 + 16 B pad = 112 B per pixel slot (zero halo as in net.hip.h); the three planes of a
-//        pixel's 8 channels are one ds_read_b128 each; an MFMA tile is whole board rows (X3Geom::PPT), which together with
-//        the 112-byte stride makes those reads bank-conflict-free; written in place (a layer's reads are complete before
-//        its epilogue starts, the block input for the skip connection stays in registers) -- or into a second buffer (PP)
-//   the input planes (small integers: exact in bf16, no split) sit in their pixel's slot: 4 planes in the 16-byte pad,
-//   DragonChess' 17 in the first 64 B (the first conv's outputs overwrite them after its reads)
+//   X    [slot][plane 0..2][16 ch] bf16 = 96 B per pixel slot (zero halo: one extra slot per board row and two extra rows, as
+//        in net.hip.h); the three planes of a pixel's 8 channels are one ds_read_b128 each.  The layout is designed against
+//        the LDS banking of MI355X_MICROARCH.md (a ds_read_b128 is served in the four lane groups {0-3, 12-15, 20-27},
+//        {4-11, 16-19, 28-31}, ..., 64 banks; a ds_write_b64 in four groups of 16 consecutive lanes, 32 banks) with
+//        tools/model/lds_banks.py:
+//          * an MFMA tile is 16 CONSECUTIVE slots -- two board rows of Connect4 with their halo column (the 16 lanes' 96-byte
+//            strides tile the 64 banks exactly); DragonChess (9 slots per row) gives lanes {0-3, 12-15} the first row of a
+//            tile and lanes 4-11 the second.  Columns that are halo slots compute garbage and are not stored.
+//          * 8-slot rows: the two 16-byte halves of a plane swap places in slots 4..7 of every 8 (X3Geom::swz), which makes
+//            the 8-byte epilogue stores 2-way instead of 4-way conflicted and costs the readers nothing (the half is part of
+//            a per-lane address that exists anyway).
+//        Round 2's layout (112-byte slots, 14-pixel tiles) ran every operand read as a 2-way conflict in one of its four lane
+//        groups: 306 LDS cycles of activation reads per layer where 168 suffice (PMC: 38 % of the LDS cycles were conflicts).
+//        Written in place (a layer's reads are complete before its epilogue starts, the block input for the skip connection
+//        stays in registers) -- or into a second buffer (PP).
+//   the input planes (small integers: exact in bf16, no split) sit in the first bytes of their pixel's slot (8 B, DragonChess'
+//   17 planes 64 B); the first conv's outputs overwrite them after its reads.
 //   the last layer leaves float32 [slot][16 ch] in the first 64 B of each interior slot for the heads.
 //   K order of a tower layer: taps (0,1), (3,4), (6,7), (2,5) as four K = 32 slices (lane group g = lane >> 4 holds
-//   channels 8 (g & 1) .. +7 of the slice's tap g >> 1), then tap 8 as one K = 16 slice (zero-extended: x3_k16).
+//   channels 8 (g & 1) .. +7 of the slice's tap g >> 1), then tap 8 -- K = 16 per plane pair -- as THREE K = 32 products by
+//   concatenating planes along K:  [w1|w1].[x1;x2] + [w2|w2].[x1;x2] + [w1|w3].[x3;x1]  (lane groups 0,1 hold the first
+//   plane of each pair, groups 2,3 the second): 27 MFMAs per tile and layer instead of 30 with zero-extended K = 16 operands.
+//   Products are accumulated in ONE order in every variant (default / LEAN / PP): per slice w3 x1, w2 x1, w1 x1, w2 x2, w1 x2,
+//   w1 x3, then the tap-8 products in the order above reversed -- so all launch structures give the same bits.
 //   Weights: pre-split and pre-swizzled on the host into the A-operand lane order (engine.hip: pack_x3); planes 1 and 2 may
 //   live in the caller's LDS, plane 3 always streams from L2 a layer ahead.
 //   Callers: k_net_x3 (bb_net_eval, lock-step and asynchronous-round search), k_selfplay_queue (mega2.hip.h),
@@ -44,35 +59,53 @@ struct X3Geom {
     static_assert(CIN <= 32, "the first conv packs at most 32 input planes per tap");
     static_assert(HW <= 64, "one lane per pixel in the heads");
     static constexpr bool WIDE_IN = CIN > 4;                        // DragonChess (17 planes): one K = 32 slice per tap
-    static constexpr int SLOTS = (H + 2) * (W + 1) + 1;
-    // pixels per 16-column MFMA tile: whole board rows (Connect4: 2 rows = 14 pixels, the last two columns repeat the 14th).
-    // Slots of two adjacent rows are distinct modulo 16, so the 16 lanes of an operand read hit 16 different bank groups;
-    // 16 consecutive pixels span three rows and two of them collide.
-    static constexpr int PPT = (W < 16 && HW > 16) ? (16 / W) * W : (HW < 16 ? HW : 16);
-    static constexpr int NT = (HW + PPT - 1) / PPT;
-    // bytes of X per slot: 3 planes x 32 B + 16 B of padding -- at 96 B the 16 pixels of a tile start 24 banks apart (period
-    // 8: every ds_read_b128 of a pixel plane is a 2-way bank conflict), at 112 B they start 28 banks apart (period 16: none)
-    static constexpr int SLOT_B = 112;
+    static constexpr int RS = W + 1;                                // slots per board row: the pixels + one zero halo column
+    static constexpr int S0 = RS + 1;                               // slot of pixel (0, 0)
+    // MFMA tile = 16 pixel columns.  CONTIG (8 or 4 slots per row): 16 consecutive slots starting at S0 + 16 t, halo columns
+    // included (their results are not stored).  Otherwise (DragonChess, 9 slots per row): two board rows, lanes {0-3, 12-15}
+    // the first and lanes 4-11 the second -- the lane groups of a ds_read_b128 then see 16 different bank quads either way.
+    static constexpr bool CONTIG = (16 % RS) == 0;
+    static_assert(CONTIG || (W == 8 && H % 2 == 0), "tile shapes exist for 4-, 8- and 9-slot rows");
+    static constexpr int NT = CONTIG ? (H * RS + 15) / 16 : H / 2;
+    static constexpr bool SWZ = RS == 8;                            // see swz()
+    static constexpr int SLOT_B = 96;                               // 3 planes x 16 channels x bf16
+    static constexpr int SLOTS_BOARD = (H + 2) * RS + 2;
+    static constexpr int SLOTS_TILES = CONTIG ? S0 + 16 * NT + RS + 2 : 0; // the last tile's halo columns read this far
+    static constexpr int SLOTS = SLOTS_BOARD > SLOTS_TILES ? SLOTS_BOARD : SLOTS_TILES;
     static constexpr int X_B = SLOTS * SLOT_B;
-    static constexpr int INP_B = 0; // the input planes sit in their own X slot: wide ([32 ch] bf16) in its first 64 B, narrow ([4 ch]) in the pad
-    static constexpr int INP_OFF = WIDE_IN ? 0 : 96;
     static constexpr int STATE_B = ((int)sizeof(typename G::State) + 15) / 16 * 16;
-    static constexpr int WAVE_BYTES = X_B + INP_B + STATE_B;
-    static constexpr int WAVE_BYTES_PP = 2 * X_B + INP_B + STATE_B; // two activation buffers (net_body_x3 PP: DragonChess kernel)
-    // packed weights (bytes).  A tower layer's first two planes (4 slices x 2 planes x 64 lanes x 16 B + tap 8: 2 planes x 64
-    // lanes x 8 B) are what the persistent kernel keeps in LDS; the third plane (one product in six reads it) is a separate
-    // array that every kernel streams from L2, a layer ahead -- with all three planes in LDS only 5 network waves fit a CU.
-    static constexpr int LAYER12_B = 4 * 2 * 64 * 16 + 2 * 64 * 8; // 9 216
-    static constexpr int LAYER3_B = 4 * 64 * 16 + 64 * 8;          // 4 608
-    // first conv, 3 planes: narrow input -- taps 0..7 (K = 32) + tap 8 (K = 16); wide input -- 9 taps x (K = 32: 32 planes)
-    static constexpr int W0_B = WIDE_IN ? 9 * 3 * 64 * 16 : 3 * 64 * 16 + 3 * 64 * 8;
+    static constexpr int WAVE_BYTES = X_B + STATE_B;
+    static constexpr int WAVE_BYTES_PP = 2 * X_B + STATE_B; // two activation buffers (net_body_x3 PP: DragonChess kernel)
+    // slot of column nn of tile t
+    __host__ __device__ static constexpr int tile_slot(int t, int nn) {
+        if (CONTIG) return S0 + 16 * t + nn;
+        const int second = (nn >= 4 && nn < 12) ? 1 : 0, col = nn < 4 ? nn : (nn < 12 ? nn - 4 : nn - 8);
+        return (2 * t + second + 1) * RS + col + 1;
+    }
+    // ... is a pixel of the board (else a halo slot: computed, never stored)
+    __host__ __device__ static constexpr bool tile_valid(int t, int nn) {
+        if (!CONTIG) return true;
+        const int rel = 16 * t + nn;
+        return rel % RS < W && rel / RS < H;
+    }
+    // 1: the two 16-byte halves of every plane of this slot are stored swapped (8-slot rows; invariant under row shifts)
+    __host__ __device__ static constexpr int swz(int slot) { return SWZ ? (slot >> 2) & 1 : 0; }
+    // packed weights (bytes).  A tower layer's first two planes (4 slices x 2 planes x 64 lanes x 16 B + tap 8: 2 planes x
+    // [channel half][filter] x 16 B) are what the persistent kernel keeps in LDS; the third plane (one product in six reads it)
+    // is a separate array that every kernel streams from L2, a layer ahead -- with all three planes in LDS only 5 network
+    // waves fit a CU.  Its tap-8 entry is the whole A operand [w1|w3] of the third tap-8 product (64 lanes x 16 B).
+    static constexpr int LAYER12_B = 4 * 2 * 64 * 16 + 2 * 32 * 16; // 9 216
+    static constexpr int LAYER3_B = 4 * 64 * 16 + 64 * 16;          // 5 120
+    // first conv, 3 planes: narrow input -- taps 0..7 (K = 32) x 3 planes + tap 8's three planes side by side in ONE K = 32
+    // operand; wide input -- 9 taps x (K = 32: 32 planes) x 3 planes
+    static constexpr int W0_B = WIDE_IN ? 9 * 3 * 64 * 16 : 3 * 64 * 16 + 64 * 16;
 };
 
 struct NetX3 {             // device pointers of the packed operands (nullptr: this network has no x3 form)
     const unsigned char *w0;   // X3Geom::W0_B
     const unsigned char *wt12; // [2R] x LAYER12_B   planes 1 and 2 of the tower weights
-    const unsigned char *wt3;  // [2R] x LAYER3_B    plane 3, always read from global memory
-    const unsigned char *wt8;  // [2R] x 3 KB        tap 8 once more as a K = 32 slice ([plane][lane][16 B], lane groups 2, 3 zero): PP form
+    const unsigned char *wt3;  // [2R] x LAYER3_B    plane 3 (+ the [w1|w3] tap-8 operand), always read from global memory
+    const unsigned char *wt8;  // [2R] x 3 KB        tap 8's three A operands [w1|w1], [w2|w2], [w1|w3] as 64-lane images: PP form
 };
 
 __device__ __forceinline__ unsigned bf16_bits(float v) { // round to nearest even, as v_cvt_pk_bf16_f32 does for finite values
@@ -80,12 +113,20 @@ __device__ __forceinline__ unsigned bf16_bits(float v) { // round to nearest eve
     return (unsigned)__builtin_bit_cast(unsigned short, h);
 }
 
-// The 9th tap has only 16 channels of K.  v_mfma_f32_16x16x16_bf16 costs the same 17 cycles as the K = 32 instruction on
-// gfx950 (tools/micro/mfma_rate.hip), and mixing the two on one accumulator needs care: with K = 32 directly followed by
-// K = 16 on the same registers (ROCm 7.2) the second read its SrcC before the first had written it and a whole MFMA's
-// contribution was lost -- no wait states are inserted (tests/test_gpu_net.py: ..._every_tap_and_plane_contributes).  So a
-// K = 16 operand (4 bf16 per lane: channels 4g .. 4g + 3) is zero-extended to the K = 32 form (the upper four k slots of
-// every lane group multiply zero by zero) and the tower uses one MFMA kind throughout.
+// A compiler hazard met on the way to the tap-8 form above (ROCm 7.2, gfx950; tools/micro/mfma_mixk.hip is the repro):
+// v_mfma_f32_16x16x32_bf16 directly followed by v_mfma_f32_16x16x16_bf16 on the same accumulator -- the second read its SrcC
+// before the first had written it and a whole MFMA's contribution was lost, no wait states are inserted
+// (tests/test_gpu_net.py: ..._every_tap_and_plane_contributes).  The tower therefore uses ONE MFMA kind throughout:
+// nothing in this file (or gnet_x3.hip.h) may call __builtin_amdgcn_mfma_f32_16x16x16_bf16.
+#pragma GCC poison __builtin_amdgcn_mfma_f32_16x16x16_bf16
+
+// two 8-byte halves -> one K = 32 operand
+__device__ __forceinline__ bf16x8 x3_cat(u32x2 lo, u32x2 hi) {
+    const u32x4 both = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+// (gnet_x3.hip.h, tap 8 of a channel block: a K = 16 operand zero-extended to the K = 32 instruction)
 __device__ __forceinline__ bf16x8 x3_k16(s16x4 v) {
     const u32x2 lo = __builtin_bit_cast(u32x2, v);
     const u32x4 both = {lo[0], lo[1], 0u, 0u};
@@ -116,47 +157,48 @@ __device__ __forceinline__ void x3_split4(const f32x4 y, u32x2 &p1, u32x2 &p2, u
 // PP (with !WLDS; the caller provides X3Geom::WAVE_BYTES_PP): two activation buffers.  A lone wave per SIMD cannot hide its
 // epilogue (float32 -> three planes, ~35 vector instructions and three writes per tile) behind its own MFMAs while it
 // rewrites the buffer it reads; with a second buffer the layer runs tile by tile and tile t - 1's epilogue issues while
-// tile t's 30 MFMAs execute (a bf16 MFMA leaves 8 of its 16 cycles to the wave's vector instructions).  Tap 8 is a K = 32
-// slice with a zero upper half here, so the layer needs no switch between MFMA kinds.
-template <class G, bool WLDS, bool LEAN = false, bool PP = false>
+// tile t's 27 MFMAs execute (a bf16 MFMA leaves 8 of its 16 cycles to the wave's vector instructions).
+// HEADS_OUT (persistent kernel): the wave stops after the three pooled head activations (R, R0, R1) and hands them to the
+// caller's `pooled_out` -- the value / policy tails (head_one) then run on the tree wave that picks the result up.
+#ifdef BB_DIAG
+#define X3_DBG(bit) (nd.dbg & (bit)) // ablation switches of the diagnostic build (bb_timing_net; results are wrong when set)
+#else
+#define X3_DBG(bit) false
+#endif
+template <class G, bool WLDS, bool LEAN = false, bool PP = false, bool HEADS_OUT = false>
 __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, int n, int pos0, const int *slot_list,
                                             unsigned char *wl, const typename G::State *states, const int8_t *planes,
                                             const uint32_t *game_id, const int32_t *serial, int noise, float *value_out,
                                             float *logits_out, float *policy_out, int pstride, bool zero_lds,
-                                            WideHead *compact = nullptr, const float *noise_ready = nullptr) {
+                                            WideHead *compact = nullptr, const float *noise_ready = nullptr,
+                                            float *pooled_out = nullptr) {
     using XG = X3Geom<G>;
-    constexpr int W = XG::W, CIN = XG::CIN, HW = XG::HW, NT = XG::NT, SB = XG::SLOT_B;
+    constexpr int W = XG::W, CIN = XG::CIN, HW = XG::HW, NT = XG::NT, SB = XG::SLOT_B, RS = XG::RS;
     constexpr bool WIDE_IN = XG::WIDE_IN;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, nn = lane & 15, gh = g >> 1, gl = g & 1;
     static_assert(!PP || !WLDS, "the two-buffer form keeps its weights in registers, a layer ahead");
     unsigned char *X = wl;
     unsigned char *X2 = wl + XG::X_B; // (PP only)
-    typename G::State *sst = (typename G::State *)(wl + (PP ? 2 : 1) * XG::X_B + XG::INP_B);
+    typename G::State *sst = (typename G::State *)(wl + (PP ? 2 : 1) * XG::X_B);
     auto OI = [&](int pos) { return slot_list ? slot_list[pos] : pos; };
     const bool live = pos0 < n;
 #ifdef BB_STAMPS_NET
     long long _ns = clock64();
 #endif
-    if (nd.dbg & 32) { // debug: prove the kernel runs and writes
-        if (lane == 0 && value_out) value_out[OI(pos0)] = 123.0f + pos0;
-        return;
-    }
 
     // ---- prologue: the board, the first conv's operands, zero fill -------------------------------------------------
     const typename G::State my_state = planes ? G::initial() : states[OI(live ? pos0 : 0)];
     const unsigned char *w0p = x3.w0;
     bf16x8 w0a[WIDE_IN ? 27 : 3]; // wide input: [tap][plane], all requested now (L2), consumed tap by tap
-    s16x4 w0b[3];
+    bf16x8 w0b;                   // narrow input: tap 8's three weight planes side by side in one K = 32 operand
     if constexpr (WIDE_IN) {
 #pragma unroll
         for (int i = 0; i < 27; i++) w0a[i] = *(const bf16x8 *)(w0p + (i * 64 + lane) * 16);
     } else {
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            w0a[q] = *(const bf16x8 *)(w0p + (q * 64 + lane) * 16);
-            w0b[q] = *(const s16x4 *)(w0p + 3 * 64 * 16 + (q * 64 + lane) * 8);
-        }
+        for (int q = 0; q < 3; q++) w0a[q] = *(const bf16x8 *)(w0p + (q * 64 + lane) * 16);
+        w0b = *(const bf16x8 *)(w0p + (3 * 64 + lane) * 16);
     }
     const f32x4 bias0 = *(const f32x4 *)(nd.epi + 4 * g), scale0 = *(const f32x4 *)(nd.epi + 16 + 4 * g),
                 shift0 = *(const f32x4 *)(nd.epi + 32 + 4 * g);
@@ -181,14 +223,14 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             unsigned b[32];
 #pragma unroll
             for (int c = 0; c < 32; c++) b[c] = c < CIN ? __float_as_uint((float)v[c]) >> 16 : 0u;
-            unsigned char *dst = X + ((y + 1) * (W + 1) + (x + 1)) * SB;
+            unsigned char *dst = X + ((y + 1) * RS + (x + 1)) * SB;
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 *(u32x4 *)(dst + 16 * k) = u32x4{b[8 * k] | (b[8 * k + 1] << 16), b[8 * k + 2] | (b[8 * k + 3] << 16),
                                                  b[8 * k + 4] | (b[8 * k + 5] << 16), b[8 * k + 6] | (b[8 * k + 7] << 16)};
         }
     } else
-    if (lane < HW && live) { // input planes of pixel `lane`: 4 x bf16 (the int8 plane values are exact in bf16)
+    if (lane < HW && live) { // input planes of pixel `lane`: 4 x bf16 (the int8 plane values are exact in bf16) in the first 8 B of its slot
         const int y = lane / W, x = lane % W;
         int8_t v[4] = {0, 0, 0, 0};
         if (planes) {
@@ -204,26 +246,34 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
         unsigned b[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) b[c] = __float_as_uint((float)v[c]) >> 16;
-        *(u32x2 *)(X + ((y + 1) * (W + 1) + (x + 1)) * SB + XG::INP_OFF) = u32x2{b[0] | (b[1] << 16), b[2] | (b[3] << 16)};
+        *(u32x2 *)(X + ((y + 1) * RS + (x + 1)) * SB) = u32x2{b[0] | (b[1] << 16), b[2] | (b[3] << 16)};
     }
-    // ---- per-tile addressing (bytes).  Offsets are biased by the window's top-left tap (TAP0 slots), so every tap is a
-    // non-negative immediate; MFMA columns past the last pixel repeat the last pixel (same values to the same addresses).
-    constexpr int TAP0 = (W + 1) + 1;
-    int aA[NT], aB[NT], aC[NT], aO[NT], iA[NT];
-    auto tapoff = [](int tap) { return (tap / 3) * (W + 1) + (tap % 3); };
+    // ---- per-tile addressing (bytes; X3Geom: tile_slot, swz).  Offsets are biased by the window's top-left tap, so every
+    // tap of a row slice is a non-negative immediate on one address register.
+    // A tile's slots are the previous tile's + TS bytes (the swizzle repeats every 8 slots), so one address register per
+    // operand kind serves every tile: the tile and tap displacements are immediates of the ds instructions.
+    constexpr int TS = (XG::CONTIG ? 16 : 2 * RS) * SB;
+    static_assert(XG::tile_slot(NT - 1, 5) * SB == XG::tile_slot(0, 5) * SB + (NT - 1) * TS && (!XG::SWZ || XG::swz(XG::tile_slot(1, 9)) == XG::swz(XG::tile_slot(0, 9))), "tile stride");
+    auto tapoff = [](int tap) { return (tap / 3) * RS + (tap % 3); };
     const int t0off = tapoff(2 * g) * SB, t1off = tapoff(2 * g + 1) * SB; // first conv: lane group g holds taps 2g, 2g + 1
+    const int s0 = XG::tile_slot(0, nn);
+    const int aA0 = (s0 - RS - 1 + gh) * SB + ((gl ^ XG::swz(s0 - 1 + gh)) << 4);   // slices (3r, 3r + 1): + r RS SB
+    const int aB0 = (s0 + (gh - 1) * RS + 1) * SB + ((gl ^ XG::swz(s0 + 1)) << 4);  // slice (2, 5)
+    const int aC0 = (s0 + RS + 1) * SB + ((gl ^ XG::swz(s0 + 1)) << 4);             // tap 8: [x1;x2] at + c81, [x3;x1] at + c83
+    const int aC1 = aC0 + gh * 32, aC3 = aC0 + (1 - gh) * 64;
+    const int aO0 = s0 * SB + ((g ^ (XG::swz(s0) << 1)) << 3);                      // this lane's 4 output channels of its pixel, plane 0
+    const int aF0 = s0 * SB + g * 16;                                               // ... as float32 (last layer, for the heads)
+    const int iA0 = (s0 - RS - 1) * SB;
+    bool wv[NT]; // column nn of tile t is a pixel (else a halo slot: computed, not stored)
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        int q = t * XG::PPT + (nn < XG::PPT ? nn : XG::PPT - 1);
-        int qq = q < HW ? q : HW - 1;
-        int y = qq / W, x = qq % W;
-        int base = ((y + 1) * (W + 1) + (x + 1) - TAP0);
-        aA[t] = base * SB + gh * SB + gl * 16;             // slices (3r, 3r + 1): + r (W + 1) SB
-        aB[t] = base * SB + gh * (W + 1) * SB + gl * 16;   // slice (2, 5): + 2 SB
-        aC[t] = base * SB + g * 8;                          // tap 8 (K = 16: channels 4g .. 4g + 3): + (2 (W + 1) + 2) SB
-        aO[t] = (base + TAP0) * SB + g * 8;                 // this lane's 4 output channels of its pixel, plane 0
-        iA[t] = base * SB + XG::INP_OFF;
-    }
+    for (int t = 0; t < NT; t++) wv[t] = XG::tile_valid(t, nn);
+#define aA(t) (aA0 + (t) * TS)
+#define aB(t) (aB0 + (t) * TS)
+#define aC1(t) (aC1 + (t) * TS)
+#define aC3(t) (aC3 + (t) * TS)
+#define aO(t) (aO0 + (t) * TS)
+#define aF(t) (aF0 + (t) * TS)
+#define iA(t) (iA0 + (t) * TS)
     wave_lds_handover();
     NSTAMP(0);
     f32x4 acc[NT], sk[NT];
@@ -236,32 +286,29 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             for (int tap = 0; tap < 9; tap++) {
                 bf16x8 b[NT];
 #pragma unroll
-                for (int t = 0; t < NT; t++) b[t] = *(const bf16x8 *)(X + aC[t] + g * 8 + tapoff(tap) * SB); // (aC = base SB + 8 g)
+                for (int t = 0; t < NT; t++) b[t] = *(const bf16x8 *)(X + iA(t) + g * 16 + tapoff(tap) * SB);
 #pragma unroll
                 for (int q = 2; q >= 0; q--)
 #pragma unroll
                     for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[tap * 3 + q], b[t], acc[t], 0, 0, 0);
             }
-            wave_lds_handover(); // the inputs are read (their values feed the MFMAs above) before the output planes overwrite them
         } else {
-        bf16x8 b[NT];
-        s16x4 b8[NT];
+        bf16x8 b[NT], b8[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            u32x2 lo = *(const u32x2 *)(X + iA[t] + t0off), hi = *(const u32x2 *)(X + iA[t] + t1off);
-            u32x4 both = {lo[0], lo[1], hi[0], hi[1]};
-            b[t] = __builtin_bit_cast(bf16x8, both);
-            b8[t] = __builtin_bit_cast(s16x4, *(const u32x2 *)(X + iA[t] + tapoff(8) * SB));
+            const u32x2 lo = *(const u32x2 *)(X + iA(t) + t0off), hi = *(const u32x2 *)(X + iA(t) + t1off);
+            const u32x2 e8 = *(const u32x2 *)(X + iA(t) + tapoff(8) * SB);
+            b[t] = x3_cat(lo, hi);
+            b8[t] = x3_cat(e8, e8); // lane group 0: [w1 | w2] . [x ; x], group 1: [w3 | 0] . [x ; x], groups 2, 3: zero weights
         }
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b, b8[t], acc[t], 0, 0, 0);
 #pragma unroll
         for (int q = 2; q >= 0; q--) // small terms first
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[q], b[t], acc[t], 0, 0, 0);
-#pragma unroll
-        for (int q = 2; q >= 0; q--)
-#pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(w0b[q]), x3_k16(b8[t]), acc[t], 0, 0, 0);
         }
+        wave_lds_handover(); // the inputs are read (their values feed the MFMAs above) before the output planes overwrite them
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             f32x4 y;
@@ -270,30 +317,27 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             sk[t] = y;
             u32x2 p1, p2, p3;
             x3_split4(y, p1, p2, p3);
-            *(u32x2 *)(X + aO[t]) = p1;
-            *(u32x2 *)(X + aO[t] + 32) = p2;
-            *(u32x2 *)(X + aO[t] + 64) = p3;
+            if (wv[t]) {
+                *(u32x2 *)(X + aO(t)) = p1;
+                *(u32x2 *)(X + aO(t) + 32) = p2;
+                *(u32x2 *)(X + aO(t) + 64) = p3;
+            }
         }
-    }
-    if (nd.dbg & 64) { // debug: first conv output channel 0 of pixel `pos0 % HW`... lane 0 holds pixel 0 channels 0..3
-        if (lane == 0 && value_out) value_out[OI(pos0)] = sk[0][0];
-        return;
     }
     wave_lds_handover();
     NSTAMP(1);
     // ---- residual tower ------------------------------------------------------------------------------------------------
-    const int R_eff = (nd.dbg & 2) ? 0 : nd.R;
+    const int R_eff = X3_DBG(2) ? 0 : nd.R;
     const int L = 2 * R_eff;
     // plane 3 of the tower weights comes from L2: the five operands of a layer are requested a layer ahead.  So are planes 1
     // and 2 when the caller does not keep them in LDS (!WLDS: batch kernels and the DragonChess wave-per-game kernel, whose
-    // LDS holds the 4032-wide head): 54 registers of weights in flight, which a 256-thread workgroup can afford.
-    bf16x8 w3c[4], w12c[WLDS ? 1 : 4][2];
-    s16x4 w3c8, w12c8[2];
+    // LDS holds the 4032-wide head): 56 registers of weights in flight, which a 256-thread workgroup can afford.
+    bf16x8 w3c[5], w12c[WLDS ? 1 : 5][2];
+    const int w8lane = (gl * 16 + nn) * 16; // tap 8, planes 1 and 2: [channel half][filter] x 16 B (both lane-group halves read the same)
     auto request_layer = [&](int l) __attribute__((always_inline)) {
         const unsigned char *g3 = x3.wt3 + (size_t)l * XG::LAYER3_B;
 #pragma unroll
-        for (int sl = 0; sl < 4; sl++) w3c[sl] = *(const bf16x8 *)(g3 + (sl * 64 + lane) * 16);
-        w3c8 = *(const s16x4 *)(g3 + 4 * 64 * 16 + lane * 8);
+        for (int sl = 0; sl < 5; sl++) w3c[sl] = *(const bf16x8 *)(g3 + (sl * 64 + lane) * 16); // (sl 4: the [w1|w3] operand of tap 8)
         if constexpr (!WLDS) {
             const unsigned char *g12 = x3.wt12 + (size_t)l * XG::LAYER12_B;
 #pragma unroll
@@ -301,7 +345,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
 #pragma unroll
                 for (int q = 0; q < 2; q++) w12c[sl][q] = *(const bf16x8 *)(g12 + ((sl * 2 + q) * 64 + lane) * 16);
 #pragma unroll
-            for (int q = 0; q < 2; q++) w12c8[q] = *(const s16x4 *)(g12 + 4 * 2 * 64 * 16 + (q * 64 + lane) * 8);
+            for (int q = 0; q < 2; q++) w12c[4][q] = *(const bf16x8 *)(g12 + 4 * 2 * 64 * 16 + q * 512 + w8lane);
         }
     };
     if (L > 0 && !PP) request_layer(0);
@@ -314,13 +358,12 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = bias;
         }
-        // slice s: 0,1,2 = taps (3s, 3s + 1) at row s; 3 = taps (2, 5); then tap 8 (K = 16 instructions).
+        // slice s: 0,1,2 = taps (3s, 3s + 1) at row s; 3 = taps (2, 5); then tap 8 (three plane-concatenated products).
         // Operands roll through the registers plane by plane: while the 3 NT MFMAs that use the pixels' first plane run
         // (w3 x1, w2 x1, w1 x1 for every tile), the second plane arrives; during its 2 NT MFMAs the third plane, the next
         // slice's weights and its first plane arrive -- a third of the registers of a whole-slice double buffer (which
         // measured slower: spills).
-        auto xoff = [&](int s, int t) __attribute__((always_inline)) { return s < 3 ? aA[t] + s * (W + 1) * SB : aB[t] + 2 * SB; };
-        constexpr int T8 = (2 * (W + 1) + 2) * SB;
+        auto xoff = [&](int s, int t) __attribute__((always_inline)) { return s < 3 ? aA(t) + s * RS * SB : aB(t); };
         if constexpr (LEAN) {
             static_assert(!LEAN || WLDS, "the in-place schedule reads its weights from LDS");
 #pragma unroll
@@ -331,36 +374,31 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
                     const bf16x8 xa = *(const bf16x8 *)(X + xoff(s, t)), xb = *(const bf16x8 *)(X + xoff(s, t) + 32),
                                  xc_ = *(const bf16x8 *)(X + xoff(s, t) + 64);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3c[s], xa, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xc_, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xa, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xa, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xc_, acc[t], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            const s16x4 va = *(const s16x4 *)(wp + 4 * 2 * 64 * 16 + (0 * 64 + lane) * 8), vb = *(const s16x4 *)(wp + 4 * 2 * 64 * 16 + (1 * 64 + lane) * 8);
-            s16x4 ya[NT], yb[NT], yc[NT];
+            const bf16x8 a1 = *(const bf16x8 *)(wp + 4 * 2 * 64 * 16 + w8lane), a2 = *(const bf16x8 *)(wp + 4 * 2 * 64 * 16 + 512 + w8lane);
+            const bf16x8 a3 = w3c[4];
+            bf16x8 y1[NT], y3[NT];
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                ya[t] = *(const s16x4 *)(X + aC[t] + T8);
-                yb[t] = *(const s16x4 *)(X + aC[t] + T8 + 32);
-                yc[t] = *(const s16x4 *)(X + aC[t] + T8 + 64);
+                y1[t] = *(const bf16x8 *)(X + aC1(t));
+                y3[t] = *(const bf16x8 *)(X + aC3(t));
             }
-            const s16x4 w38 = w3c8;
             if (l + 1 < L) request_layer(l + 1);
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(w38), x3_k16(ya[t]), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(vb), x3_k16(yb[t]), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(va), x3_k16(yc[t]), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(vb), x3_k16(ya[t]), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(va), x3_k16(yb[t]), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(va), x3_k16(ya[t]), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, y3[t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, y1[t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, y1[t], acc[t], 0, 0, 0);
             }
         } else {
         bf16x8 wc[2], wn[2], x0[NT], x1[NT], x2[NT];
-        s16x4 w8[2], y0[NT], y1[NT], y2[NT];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             if constexpr (WLDS) wc[q] = *(const bf16x8 *)(wp + ((0 * 2 + q) * 64 + lane) * 16);
@@ -390,14 +428,14 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
                 }
 #pragma unroll
                 for (int t = 0; t < NT; t++) x0[t] = *(const bf16x8 *)(X + xoff(s + 1, t));
-            } else {
+            } else { // tap 8: [x3;x1] into the first-plane registers, [w1|w1] / [w2|w2] into the next-slice weight registers
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
-                    if constexpr (WLDS) w8[q] = *(const s16x4 *)(wp + 4 * 2 * 64 * 16 + (q * 64 + lane) * 8);
-                    else w8[q] = w12c8[q];
+                    if constexpr (WLDS) wn[q] = *(const bf16x8 *)(wp + 4 * 2 * 64 * 16 + q * 512 + w8lane);
+                    else wn[q] = w12c[WLDS ? 0 : 4][q];
                 }
 #pragma unroll
-                for (int t = 0; t < NT; t++) y0[t] = *(const s16x4 *)(X + aC[t] + T8);
+                for (int t = 0; t < NT; t++) x0[t] = *(const bf16x8 *)(X + aC3(t));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -407,30 +445,21 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], x2[t], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < 4) {
 #pragma unroll
-                for (int q = 0; q < 2; q++) wc[q] = wn[q];
-            }
+            for (int q = 0; q < 2; q++) wc[q] = wn[q];
         }
+        // tap 8: [w1|w3].[x3;x1], then [w2|w2].[x1;x2] and [w1|w1].[x1;x2] on one operand read
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            y1[t] = *(const s16x4 *)(X + aC[t] + T8 + 32);
-            y2[t] = *(const s16x4 *)(X + aC[t] + T8 + 64);
-        }
-        const s16x4 w38 = w3c8;
-        if (l + 1 < L) request_layer(l + 1); // (this layer's slice registers were read for the last time above; w8 / w38 are copies)
+        for (int t = 0; t < NT; t++) x1[t] = *(const bf16x8 *)(X + aC1(t));
+        const bf16x8 a3 = w3c[4];
+        if (l + 1 < L) request_layer(l + 1); // (this layer's slice registers were read for the last time above; a3 is a copy)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(w38), x3_k16(y0[t]), acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, x0[t], acc[t], 0, 0, 0);
 #pragma unroll
         for (int q = 1; q >= 0; q--)
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(w8[q]), x3_k16(y0[t]), acc[t], 0, 0, 0);
-#pragma unroll
-        for (int q = 1; q >= 0; q--)
-#pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(w8[q]), x3_k16(y1[t]), acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3_k16(w8[0]), x3_k16(y2[t]), acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[q], x1[t], acc[t], 0, 0, 0);
         }
         // (the batch-norm constants are read here, not at the top of the layer: 8 registers less through the slices)
         const f32x4 scale = *(const f32x4 *)(ep + 16 + 4 * g), shift = *(const f32x4 *)(ep + 32 + 4 * g);
@@ -446,21 +475,23 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             }
             if constexpr (SKIP) sk[t] = y;
             if constexpr (LAST) {
-                *(f32x4 *)(X + aO[t] + g * 8) = y; // float32 [slot][16 ch]: channels 4g .. 4g + 3 at byte 16 g of the slot
+                if (wv[t]) *(f32x4 *)(X + aF(t)) = y; // float32 [slot][16 ch]: channels 4g .. 4g + 3 at byte 16 g of the slot
             } else {
                 u32x2 p1, p2, p3;
                 x3_split4(y, p1, p2, p3);
-                *(u32x2 *)(X + aO[t]) = p1;
-                *(u32x2 *)(X + aO[t] + 32) = p2;
-                *(u32x2 *)(X + aO[t] + 64) = p3;
+                if (wv[t]) {
+                    *(u32x2 *)(X + aO(t)) = p1;
+                    *(u32x2 *)(X + aO(t) + 32) = p2;
+                    *(u32x2 *)(X + aO(t) + 64) = p3;
+                }
             }
         }
         wave_lds_handover();
     };
     // ---- the same layer, tile by tile, from buffer `src` into buffer `dst` (PP) -------------------------------------------------
-    // Two named sets of layer weights (15 operands each: 5 slices x 3 planes; slice 4 = tap 8 as a K = 32 slice): a layer
-    // computes from one set while the next layer's requests fill the other -- the block loop below alternates them, so no
-    // register copies are needed.
+    // Two named sets of layer weights (15 operands each: 5 slices x 3 planes; slice 4 = tap 8's three plane-concatenated A
+    // operands): a layer computes from one set while the next layer's requests fill the other -- the block loop below
+    // alternates them, so no register copies are needed.
     struct WSet { bf16x8 w1[5], w2[5], w3[5]; };
     auto request_set = [&](WSet &ws, int l) __attribute__((always_inline)) {
         const unsigned char *g12 = as_global(x3.wt12) + (size_t)l * XG::LAYER12_B, *g3 = as_global(x3.wt3) + (size_t)l * XG::LAYER3_B,
@@ -471,24 +502,25 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             ws.w2[sl] = *(const bf16x8 *)(g12 + ((sl * 2 + 1) * 64 + lane) * 16);
             ws.w3[sl] = *(const bf16x8 *)(g3 + (sl * 64 + lane) * 16);
         }
-        ws.w1[4] = *(const bf16x8 *)(g8 + (0 * 64 + lane) * 16);
-        ws.w2[4] = *(const bf16x8 *)(g8 + (1 * 64 + lane) * 16);
-        ws.w3[4] = *(const bf16x8 *)(g8 + (2 * 64 + lane) * 16);
+        ws.w1[4] = *(const bf16x8 *)(g8 + (0 * 64 + lane) * 16); // [w1|w1]
+        ws.w2[4] = *(const bf16x8 *)(g8 + (1 * 64 + lane) * 16); // [w2|w2]
+        ws.w3[4] = *(const bf16x8 *)(g8 + (2 * 64 + lane) * 16); // [w1|w3]
     };
     auto conv_layer_pp = [&](const int l, const WSet &ws, const unsigned char *src, unsigned char *dst, auto skip_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr bool SKIP = decltype(skip_tag)::value, LAST = decltype(last_tag)::value;
         const float *ep = nd.epi + (size_t)(1 + l) * 48;
         const f32x4 bias = *(const f32x4 *)(ep + 4 * g), scale = *(const f32x4 *)(ep + 16 + 4 * g), shift = *(const f32x4 *)(ep + 32 + 4 * g);
-        auto xoff = [&](int s, int t) __attribute__((always_inline)) { return s < 3 ? aA[t] + s * (W + 1) * SB : aB[t] + 2 * SB; };
-        constexpr int T8 = (2 * (W + 1) + 2) * SB;
-        // slice 4 = tap 8: lane groups 0, 1 hold its channels 0..7, 8..15; groups 2, 3 re-read them against zero weights
-        auto xaddr = [&](int s, int t) __attribute__((always_inline)) { return s < 4 ? xoff(s, t) : aA[t] - gh * SB + T8; };
+        // operand q of slice s: slices 0..3 = pixel planes 1, 2, 3; slice 4 (tap 8) = [x1;x2], [x3;x1], none
+        auto xaddr = [&](int s, int t, int q) __attribute__((always_inline)) {
+            return s < 3 ? aA(t) + s * RS * SB + q * 32 : (s == 3 ? aB(t) + q * 32 : (q == 0 ? aC1(t) : aC3(t)));
+        };
+        auto nops = [](int s) { return s == 4 ? 2 : 3; };
         // operands two slices ahead: a slice is 6 MFMAs = 96 cycles, an LDS round trip of three 1 KB reads is longer
         bf16x8 xc[3], xn[3], xnn[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            xc[q] = *(const bf16x8 *)(src + xaddr(0, 0) + q * 32);
-            xn[q] = *(const bf16x8 *)(src + xaddr(1, 0) + q * 32);
+            xc[q] = *(const bf16x8 *)(src + xaddr(0, 0, q));
+            xn[q] = *(const bf16x8 *)(src + xaddr(1, 0, q));
         }
         auto epilogue = [&](int t) __attribute__((always_inline)) {
             f32x4 y;
@@ -500,35 +532,44 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             }
             if constexpr (SKIP) sk[t] = y;
             if constexpr (LAST) {
-                *(f32x4 *)(dst + aO[t] + g * 8) = y;
+                if (wv[t]) *(f32x4 *)(dst + aF(t)) = y;
             } else {
                 u32x2 p1, p2, p3;
                 x3_split4(y, p1, p2, p3);
-                *(u32x2 *)(dst + aO[t]) = p1;
-                *(u32x2 *)(dst + aO[t] + 32) = p2;
-                *(u32x2 *)(dst + aO[t] + 64) = p3;
+                if (wv[t]) {
+                    *(u32x2 *)(dst + aO(t)) = p1;
+                    *(u32x2 *)(dst + aO(t) + 32) = p2;
+                    *(u32x2 *)(dst + aO(t) + 64) = p3;
+                }
             }
         };
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             acc[t] = bias;
-            // One scheduling region per tile: its 30 MFMAs, the operand reads two slices ahead and tile t - 1's epilogue (~60 vector
-            // instructions, three writes), dealt out by the group barriers below: per slice three reads, then six times one MFMA
-            // and up to two vector instructions, which fit in the 8 cycles of its 16 that a bf16 MFMA leaves to the wave.
+            // One scheduling region per tile: its 27 MFMAs, the operand reads two slices ahead and tile t - 1's epilogue (~60 vector
+            // instructions, three writes), dealt out by the group barriers below: per slice its reads, then per MFMA up to two
+            // vector instructions, which fit in the 8 cycles of its 16 that a bf16 MFMA leaves to the wave.
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 5; s++) {
                 const int sn = (s + 2) % 5, tn = s + 2 < 5 ? t : t + 1;
                 if (tn < NT) {
 #pragma unroll
-                    for (int q = 0; q < 3; q++) xnn[q] = *(const bf16x8 *)(src + xaddr(sn, tn) + q * 32);
+                    for (int q = 0; q < 3; q++)
+                        if (q < nops(sn)) xnn[q] = *(const bf16x8 *)(src + xaddr(sn, tn, q));
                 }
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w3[s], xc[0], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w2[s], xc[1], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[s], xc[2], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w2[s], xc[0], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[s], xc[1], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[s], xc[0], acc[t], 0, 0, 0);
+                if (s < 4) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w3[s], xc[0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w2[s], xc[0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[s], xc[0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w2[s], xc[1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[s], xc[1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[s], xc[2], acc[t], 0, 0, 0);
+                } else {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w3[4], xc[1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w2[4], xc[0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[4], xc[0], acc[t], 0, 0, 0);
+                }
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
                     xc[q] = xn[q];
@@ -536,15 +577,14 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
                 }
             }
             if (t > 0) epilogue(t - 1);
-#pragma unroll
-            for (int s = 0; s < 5; s++) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); // DS read
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); // VALU
-                }
-            }
+#define X3_PP_GROUP(NREAD, NMFMA)                                                                      \
+    __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0); /* DS read */                              \
+    _Pragma("unroll") for (int k = 0; k < NMFMA; k++) {                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* MFMA */                                 \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); /* VALU */                                 \
+    }
+            X3_PP_GROUP(3, 6) X3_PP_GROUP(3, 6) X3_PP_GROUP(2, 6) X3_PP_GROUP(3, 6) X3_PP_GROUP(3, 3) // (reads are two slices ahead: tap 8 has two)
+#undef X3_PP_GROUP
             __builtin_amdgcn_sched_group_barrier(0x200, 3, 0); // DS write
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -581,14 +621,17 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     float x = 0.f, x0 = 0.f, x1 = 0.f;
     if (lane < HW) {
         const int y_ = lane / W, x_ = lane % W;
-        const float *xp = (const float *)(X + ((y_ + 1) * (W + 1) + (x_ + 1)) * SB);
+        const int hs = (y_ + 1) * RS + (x_ + 1);
+        const float *xp = (const float *)(X + hs * SB);
         float av = v3[0], a0 = p6[0], a1 = p6[1];
         if (R_eff == 0) { // no tower: the first conv's output is still in its three planes
             const unsigned short *hpix = (const unsigned short *)xp;
+            const int hb = XG::swz(hs) << 1;
 #pragma unroll
             for (int c = 0; c < 16; c++) {
-                float xv = __uint_as_float((unsigned)hpix[c] << 16) + __uint_as_float((unsigned)hpix[16 + c] << 16) +
-                           __uint_as_float((unsigned)hpix[32 + c] << 16);
+                const int cc = (((c >> 2) ^ hb) << 2) | (c & 3); // where channel c sits inside a plane of this slot
+                float xv = __uint_as_float((unsigned)hpix[cc] << 16) + __uint_as_float((unsigned)hpix[16 + cc] << 16) +
+                           __uint_as_float((unsigned)hpix[32 + cc] << 16);
                 av = __builtin_fmaf(xv, vk[c], av);
                 a0 = __builtin_fmaf(xv, pk[2 * c], a0);
                 a1 = __builtin_fmaf(xv, pk[2 * c + 1], a1);
@@ -611,11 +654,27 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
         x1 = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
     }
     NSTAMP(3);
+    if constexpr (HEADS_OUT) {
+        const float R = pooled_sum(x), R0 = pooled_sum(x0), R1 = pooled_sum(x1);
+        if (lane == 0) {
+            pooled_out[0] = R;
+            pooled_out[1] = R0;
+            pooled_out[2] = R1;
+        }
+    } else {
     head_one<G>(nd, pooled_sum(x), pooled_sum(x0), pooled_sum(x1), live ? OI(pos0) : 0, live, game_id, serial, noise, value_out,
                 logits_out, policy_out, pstride, compact, noise_ready);
+    }
     NSTAMP(4);
 }
 
+#undef aA
+#undef aB
+#undef aC1
+#undef aC3
+#undef aO
+#undef aF
+#undef iA
 // bb_net_eval / lock-step and asynchronous-round search: one position per wave, four waves per workgroup, the packed
 // weights streamed from L2
 template <class G>
