@@ -188,7 +188,7 @@ struct bb_engine {
     DCEdges edges; // DragonChess only
     int32_t *d_child_action = nullptr;
     NetDev net;
-    NetX3 x3 = {nullptr, nullptr, nullptr, nullptr}; // 16-filter network of a dense game on the bf16 matrix pipe (net_x3.hip.h); null: float32 MFMA path
+    NetX3 x3 = {nullptr, nullptr, nullptr, nullptr, nullptr}; // 16-filter network of a dense game on the bf16 matrix pipe (net_x3.hip.h); null: float32 MFMA path
     size_t x3_bytes = 0;
     bool has_weights = false;
     int net_F = 0, net_C = 0;
@@ -258,6 +258,7 @@ static int engine_alloc(bb_engine *e) {
         dalloc(e, d.sims_left, n) || dalloc(e, d.pend_leaf, n) || dalloc(e, d.pend_expand, n) ||
         dalloc(e, d.path_len, n) || dalloc(e, d.game_lid, n) || dalloc(e, d.sim_serial, n) ||
         dalloc(e, d.root_W, n) || dalloc(e, d.root_pp, n) || dalloc(e, d.path, n * G::MAXPATH) ||
+        dalloc(e, d.path_N, n * G::MAXPATH) || dalloc(e, d.path_all, n * G::MAXPATH) || dalloc(e, d.path_W, n * G::MAXPATH) || dalloc(e, d.leaf_flags, n) ||
         dalloc(e, d.leaf_game_id, n) || dalloc(e, d.leaf_serial, n) || dalloc(e, d.eval_value, n) ||
         dalloc(e, d.eval_policy, n * PSTRIDE) || dalloc(e, d.ctr, n * 8) || dalloc(e, d.evals, n) || dalloc(e, d.out_action, n) ||
         dalloc(e, d.out_root_plays, n) || dalloc(e, d.out_child_plays, n * G::S) ||
@@ -309,6 +310,7 @@ static void make_views(bb_engine *e) {
         w.root += off; w.root_N += off; w.n_nodes += off; w.ply += off; w.sims_left += off; w.pend_leaf += off;
         w.pend_expand += off; w.path_len += off; w.game_lid += off; w.sim_serial += off; w.root_W += off;
         w.root_pp += off; w.path += (size_t)off * G::MAXPATH;
+        w.path_N += (size_t)off * G::MAXPATH; w.path_all += (size_t)off * G::MAXPATH; w.path_W += (size_t)off * G::MAXPATH; w.leaf_flags += off;
         w.leaf_state = (char *)d.leaf_state + (size_t)off * sizeof(typename G::State);
         w.leaf_game_id += off; w.leaf_serial += off; w.eval_value += off;
         w.eval_policy += (size_t)off * (G::GID == BB_GAME_DRAGONCHESS ? G::A : G::S);
@@ -756,8 +758,10 @@ static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slo
 //       groups 2, 3 plane 3, channels 8 (g & 1) .. + 7
 // wt8:  per layer [3][lane][8]: tap 8's three A operands [w1|w1], [w2|w2], [w1|w3] as 64-lane images (PP form)
 // (tap 8 = three K = 32 products on plane-concatenated operands: [w1|w1].[x1;x2] + [w2|w2].[x1;x2] + [w1|w3].[x3;x1], net_x3.hip.h)
+// wh:   [3][lane][8]: the head convolutions as a 16-filter K = 16 layer -- filter 0 = value conv, 1 and 2 = policy conv, the rest
+//       zero -- in the three operands of tap 8
 static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vector<uint16_t> &wt12, std::vector<uint16_t> &wt3,
-                    std::vector<uint16_t> &wt8) {
+                    std::vector<uint16_t> &wt8, std::vector<uint16_t> &wh) {
     const int F = 16, C = w->C, R = w->R;
     const bool wide = C > 4; // DragonChess: one K = 32 slice per tap, lane group g = input planes 8g .. 8g + 7
     w0.assign(wide ? (size_t)9 * 3 * 64 * 8 : (size_t)(3 * 64 * 8 + 64 * 8), 0);
@@ -787,6 +791,17 @@ static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vec
             if (q > 2) continue;
             bf16_split3(ch < C ? w->conv0_k[((size_t)8 * C + ch) * F + f] : 0.f, h);
             w0[(size_t)3 * 64 * 8 + (size_t)lane * 8 + i] = h[q];
+        }
+    }
+    wh.assign((size_t)3 * 64 * 8, 0);
+    for (int lane = 0; lane < 64; lane++) {
+        const int f = lane & 15, g = lane >> 4;
+        for (int i = 0; i < 8 && f < 3; i++) {
+            const int ch = 8 * (g & 1) + i;
+            bf16_split3(f == 0 ? w->v_conv_k[ch] : w->p_conv_k[(size_t)ch * 2 + (f - 1)], h);
+            wh[((size_t)0 * 64 + lane) * 8 + i] = h[0];
+            wh[((size_t)1 * 64 + lane) * 8 + i] = h[1];
+            wh[((size_t)2 * 64 + lane) * 8 + i] = g < 2 ? h[0] : h[2];
         }
     }
     static const int slice_taps[4][2] = {{0, 1}, {3, 4}, {6, 7}, {2, 5}};
@@ -895,9 +910,10 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     {
         const bool want = F == 16 && C <= 32 && !e->general_net && !(getenv("BB_NET_X3") && atoi(getenv("BB_NET_X3")) == 0);
         if (want) {
-            std::vector<uint16_t> xw0, xw12, xw3, xw8;
-            pack_x3(w, xw0, xw12, xw3, xw8);
-            const size_t b0 = xw0.size() * 2, b12 = xw12.size() * 2, b3 = xw3.size() * 2, b8 = xw8.size() * 2, bytes = b0 + b12 + b3 + b8;
+            std::vector<uint16_t> xw0, xw12, xw3, xw8, xwh;
+            pack_x3(w, xw0, xw12, xw3, xw8, xwh);
+            const size_t b0 = xw0.size() * 2, b12 = xw12.size() * 2, b3 = xw3.size() * 2, b8 = xw8.size() * 2, bh = xwh.size() * 2,
+                         bytes = b0 + b12 + b3 + b8 + bh;
             unsigned char *d_x = (unsigned char *)e->x3.w0;
             if (!d_x || bytes != e->x3_bytes) {
                 if (dalloc(e, d_x, bytes + 16, false)) return BB_ERR_HIP;
@@ -907,12 +923,14 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
             if (b12) HIPCHK(hipMemcpy(d_x + b0, xw12.data(), b12, hipMemcpyHostToDevice));
             if (b3) HIPCHK(hipMemcpy(d_x + b0 + b12, xw3.data(), b3, hipMemcpyHostToDevice));
             if (b8) HIPCHK(hipMemcpy(d_x + b0 + b12 + b3, xw8.data(), b8, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_x + b0 + b12 + b3 + b8, xwh.data(), bh, hipMemcpyHostToDevice));
             e->x3.w0 = d_x;
             e->x3.wt12 = d_x + b0;
             e->x3.wt3 = d_x + b0 + b12;
             e->x3.wt8 = d_x + b0 + b12 + b3;
+            e->x3.wh = d_x + b0 + b12 + b3 + b8;
         } else {
-            e->x3.w0 = e->x3.wt12 = e->x3.wt3 = e->x3.wt8 = nullptr;
+            e->x3.w0 = e->x3.wt12 = e->x3.wt3 = e->x3.wt8 = e->x3.wh = nullptr;
         }
     }
     nd.R = R;
@@ -1340,17 +1358,21 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
             TreeDev dm = d;
             // tree levels per call: 10 / 12 / 16 / 20 / 24 -> 155.6 / 155.8 / 153.6 / 151.6 / 151.2 M sims/s (Connect4 @800, bf16-pipe network)
             if (!getenv("BB_LEVEL_BUDGET")) dm.level_budget = 12;
-            k_set_i32<<<1, 1, 0, e->stream>>>(d.visit_pool, d.n_slots * rounds); // the launch's pool of visits (mega2.hip.h)
+            // the launch's visits: 7/8 dealt to the workgroups (per slot), the rest in the launch-wide pool (mega2.hip.h)
+            const int own = rounds - (rounds + 7) / 8;
+            k_set_i32<<<1, 1, 0, e->stream>>>(d.visit_pool, d.n_slots * (rounds - own));
             const int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
             const int netw = getenv("BB_QUEUE_NETW") ? atoi(getenv("BB_QUEUE_NETW")) : 8; // network waves of the 12 (tuning)
             if (e->x3.w0) { // bf16-pipe network: 8 waves of 256 VGPRs -- Connect4 5 network + 3 tree waves, TicTacToe 4 + 4
                 if constexpr (G::S <= 8) {
                     const int waves = getenv("BB_QUEUE_WAVES") ? atoi(getenv("BB_QUEUE_WAVES")) : 12;
                     const int nw = getenv("BB_QUEUE_NETW") ? netw : (waves == 12 ? 8 : 5);
-#define QX3(NW, WV) k_selfplay_queue<G, NW, true, WV><<<nb, WV * 64, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim)
+#define QX3(NW, WV) k_selfplay_queue<G, NW, true, WV><<<nb, WV * 64, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim, own)
                     if (waves == 12) { // 8 network + 4 tree waves of 168 VGPRs (default); BB_QUEUE_WAVES=8: 5 + 3 (6 + 2) waves of 256
                         if (nw == 6) QX3(6, 12);
                         else if (nw == 7) QX3(7, 12);
+                        else if (nw == 9) QX3(9, 12);
+                        else if (nw == 10) QX3(10, 12);
                         else QX3(8, 12);
                     } else {
                         if (nw == 4) QX3(4, 8);
@@ -1359,11 +1381,11 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
                     }
 #undef QX3
                 } else {
-                    k_selfplay_queue<G, 4, true, 8><<<nb, 512, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim);
+                    k_selfplay_queue<G, 4, true, 8><<<nb, 512, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim, own);
                 }
-            } else if (netw == 7) k_selfplay_queue<G, 7><<<nb, 768, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim);
-            else if (netw == 6) k_selfplay_queue<G, 6><<<nb, 768, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim);
-            else k_selfplay_queue<G, 8><<<nb, 768, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim);
+            } else if (netw == 7) k_selfplay_queue<G, 7><<<nb, 768, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim, own);
+            else if (netw == 6) k_selfplay_queue<G, 6><<<nb, 768, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim, own);
+            else k_selfplay_queue<G, 8><<<nb, 768, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim, own);
             HIPCHK(hipGetLastError());
             if (timed) {
                 HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));

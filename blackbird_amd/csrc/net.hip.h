@@ -193,7 +193,9 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
                                          float *logits_out, float *policy_out, int pstride, WideHead *compact,
                                          const float *noise_ready = nullptr) {
     constexpr int A = G::A, HW = G::H * G::W;
-    const int lane = threadIdx.x & 63;
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_)); // (keeps the addresses below inside a persistent caller's loop: see net_body_x3)
+    const int lane = lane_;
     const float *hp = nd.head;
     const int D = nd.D; // <= 64 (bb_load_weights)
     const float *d1k = hp + nd.off_d1k, *d1b = hp + nd.off_d1b, *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
@@ -201,8 +203,9 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
     auto lane_f = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
     // value head: dense_1 on the pooled activation (unit d on lane d), ReLU, dense_2 as an ordered fma chain, tanh
     const float sdv = lane < D ? fmaxf(__builtin_fmaf(R, d1k[lane], (float)HW * d1b[lane]), 0.f) : 0.f;
+    const float d2kv = lane < D ? d2k[lane] : 0.f; // (one load: a d2k[dd] per step of the chain below is a dependent LDS / L2 round trip each, ~2 k cycles at D = 16)
     float e = d2b[0];
-    for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(lane_f(sdv, dd), d2k[dd], e);
+    for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(lane_f(sdv, dd), lane_f(d2kv, dd), e);
     // tanh on the hardware exponential: 1 - 2 / (exp(2e) + 1) (v_exp_f32, v_rcp_f32: absolute error ~1e-7, the library tanhf is
     // ~60 instructions on the network wave's critical tail); saturates to +-1 through exp's overflow / underflow
     const float value = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(e * 2.88539008177792681472f) + 1.0f);
@@ -324,9 +327,20 @@ __device__ __forceinline__ float head_tree(const NetDev &nd, const float *hp, fl
     const float *d1k = hp + nd.off_d1k, *d1b = hp + nd.off_d1b, *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
     const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
     float e = d2b[0];
-    for (int dd = 0; dd < D; dd++) {
-        const float sdv = fmaxf(__builtin_fmaf(R, d1k[dd], (float)HW * d1b[dd]), 0.f);
-        e = __builtin_fmaf(sdv, d2k[dd], e);
+    { // (four units per round trip: the three parameter rows are 16-byte aligned in the packed head -- engine.hip `push`)
+        int dd = 0;
+        for (; dd + 4 <= D; dd += 4) {
+            const f32x4 k1 = *(const f32x4 *)(d1k + dd), b1 = *(const f32x4 *)(d1b + dd), k2 = *(const f32x4 *)(d2k + dd);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float sdv = fmaxf(__builtin_fmaf(R, k1[r], (float)HW * b1[r]), 0.f);
+                e = __builtin_fmaf(sdv, k2[r], e);
+            }
+        }
+        for (; dd < D; dd++) {
+            const float sdv = fmaxf(__builtin_fmaf(R, d1k[dd], (float)HW * d1b[dd]), 0.f);
+            e = __builtin_fmaf(sdv, d2k[dd], e);
+        }
     }
     const float value = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(e * 2.88539008177792681472f) + 1.0f);
     const bool act = lane < A;

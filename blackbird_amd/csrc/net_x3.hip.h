@@ -106,6 +106,7 @@ struct NetX3 {             // device pointers of the packed operands (nullptr: t
     const unsigned char *wt12; // [2R] x LAYER12_B   planes 1 and 2 of the tower weights
     const unsigned char *wt3;  // [2R] x LAYER3_B    plane 3 (+ the [w1|w3] tap-8 operand), always read from global memory
     const unsigned char *wt8;  // [2R] x 3 KB        tap 8's three A operands [w1|w1], [w2|w2], [w1|w3] as 64-lane images: PP form
+    const unsigned char *wh;   // 3 KB               the two 1x1 head convolutions (value: 1 filter, policy: 2) as the same three operands
 };
 
 __device__ __forceinline__ unsigned bf16_bits(float v) { // round to nearest even, as v_cvt_pk_bf16_f32 does for finite values
@@ -133,21 +134,31 @@ __device__ __forceinline__ bf16x8 x3_k16(s16x4 v) {
     return __builtin_bit_cast(bf16x8, both);
 }
 
-// y[0..3] -> three bf16 planes, each packed as 2 dwords (4 x bf16)
+// y[0..3] -> three bf16 planes, each packed as 2 dwords (4 x bf16).  Pairs go through v_cvt_pk_bf16_f32 (two roundings per
+// instruction, the pair already packed) and come back as floats by a shift / a mask: 18 vector instructions per four values
+// where converting and packing element by element took 35 -- the epilogues are half of a network wave's vector instructions.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) { // round to nearest even, as bf16_bits does
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 __device__ __forceinline__ void x3_split4(const f32x4 y, u32x2 &p1, u32x2 &p2, u32x2 &p3) {
+    unsigned a[2], b[2], c[2];
     float r1[4], r2[4];
-    unsigned a[4], b[4], c[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        a[r] = bf16_bits(y[r]);
-        r1[r] = y[r] - __uint_as_float(a[r] << 16);
-        b[r] = bf16_bits(r1[r]);
-        r2[r] = r1[r] - __uint_as_float(b[r] << 16);
-        c[r] = bf16_bits(r2[r]);
+    for (int h = 0; h < 2; h++) {
+        a[h] = cvt_pk_bf16(y[2 * h], y[2 * h + 1]);
+        r1[2 * h] = y[2 * h] - __uint_as_float(a[h] << 16);
+        r1[2 * h + 1] = y[2 * h + 1] - __uint_as_float(a[h] & 0xffff0000u);
+        b[h] = cvt_pk_bf16(r1[2 * h], r1[2 * h + 1]);
+        r2[2 * h] = r1[2 * h] - __uint_as_float(b[h] << 16);
+        r2[2 * h + 1] = r1[2 * h + 1] - __uint_as_float(b[h] & 0xffff0000u);
+        c[h] = cvt_pk_bf16(r2[2 * h], r2[2 * h + 1]);
     }
-    p1 = u32x2{a[0] | (a[1] << 16), a[2] | (a[3] << 16)};
-    p2 = u32x2{b[0] | (b[1] << 16), b[2] | (b[3] << 16)};
-    p3 = u32x2{c[0] | (c[1] << 16), c[2] | (c[3] << 16)};
+    p1 = u32x2{a[0], a[1]};
+    p2 = u32x2{b[0], b[1]};
+    p3 = u32x2{c[0], c[1]};
 }
 
 // WLDS: the packed weights (x3.w0 / x3.wt, nd.epi, nd.head) are in LDS (persistent kernel) -- else global (L2-resident).
@@ -175,7 +186,12 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     using XG = X3Geom<G>;
     constexpr int W = XG::W, CIN = XG::CIN, HW = XG::HW, NT = XG::NT, SB = XG::SLOT_B, RS = XG::RS;
     constexpr bool WIDE_IN = XG::WIDE_IN;
-    const int lane = threadIdx.x & 63;
+    // (opaque to the optimiser: inside a persistent kernel's loop everything derived from the lane number is loop-invariant --
+    // the compiler hoists the head / prologue / first-conv addresses out of the loop, holds them through the tower and spills
+    // them; each reload is a scratch round trip with a full vmcnt wait, ~4 k cycles per evaluation in the heads alone)
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_));
+    const int lane = lane_;
     const int g = lane >> 4, nn = lane & 15, gh = g >> 1, gl = g & 1;
     static_assert(!PP || !WLDS, "the two-buffer form keeps its weights in registers, a layer ahead");
     unsigned char *X = wl;
@@ -262,7 +278,8 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     const int aC0 = (s0 + RS + 1) * SB + ((gl ^ XG::swz(s0 + 1)) << 4);             // tap 8: [x1;x2] at + c81, [x3;x1] at + c83
     const int aC1 = aC0 + gh * 32, aC3 = aC0 + (1 - gh) * 64;
     const int aO0 = s0 * SB + ((g ^ (XG::swz(s0) << 1)) << 3);                      // this lane's 4 output channels of its pixel, plane 0
-    const int aF0 = s0 * SB + g * 16;                                               // ... as float32 (last layer, for the heads)
+    const int aH0 = s0 * SB + ((gl ^ XG::swz(s0)) << 4);                            // the pixel itself (head convolutions): planes as in tap 8
+    const int aH1 = aH0 + gh * 32, aH3 = aH0 + (1 - gh) * 64;
     const int iA0 = (s0 - RS - 1) * SB;
     bool wv[NT]; // column nn of tile t is a pixel (else a halo slot: computed, not stored)
 #pragma unroll
@@ -272,7 +289,8 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
 #define aC1(t) (aC1 + (t) * TS)
 #define aC3(t) (aC3 + (t) * TS)
 #define aO(t) (aO0 + (t) * TS)
-#define aF(t) (aF0 + (t) * TS)
+#define aH1(t) (aH1 + (t) * TS)
+#define aH3(t) (aH3 + (t) * TS)
 #define iA(t) (iA0 + (t) * TS)
     wave_lds_handover();
     NSTAMP(0);
@@ -474,9 +492,8 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
                 y[r] = fmaxf(v, 0.f);
             }
             if constexpr (SKIP) sk[t] = y;
-            if constexpr (LAST) {
-                if (wv[t]) *(f32x4 *)(X + aF(t)) = y; // float32 [slot][16 ch]: channels 4g .. 4g + 3 at byte 16 g of the slot
-            } else {
+            {
+                (void)LAST; // (the last layer writes its planes like every other: the head convolutions are MFMAs too)
                 u32x2 p1, p2, p3;
                 x3_split4(y, p1, p2, p3);
                 if (wv[t]) {
@@ -531,9 +548,8 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
                 y[r] = fmaxf(v, 0.f);
             }
             if constexpr (SKIP) sk[t] = y;
-            if constexpr (LAST) {
-                if (wv[t]) *(f32x4 *)(dst + aF(t)) = y;
-            } else {
+            {
+                (void)LAST;
                 u32x2 p1, p2, p3;
                 x3_split4(y, p1, p2, p3);
                 if (wv[t]) {
@@ -615,43 +631,36 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     }
     (void)L;
     NSTAMP(2);
-    // ---- heads: pixel p on lane p ---------------------------------------------------------------------------------------
+    // ---- heads: the value (1 filter) and policy (2 filters) 1x1 convolutions are one more K = 16 "tap" on the matrix pipe --
+    // rows 0..2 of a 16-filter operand, the three plane-concatenated products of tap 8 at the pixel itself -- then BN + ReLU and
+    // the spatial sums: lane (g = 0, nn) holds the three head activations of column nn of every tile.  (Round 2 formed them
+    // on the vector ALUs from a float32 copy of the last layer: 48 fmas and four 16-byte reads per pixel, 2.0 k cycles.)
     const float *hp = nd.head;
-    const float *vk = hp + nd.off_vk, *v3 = hp + nd.off_v3, *pk = hp + nd.off_pk, *p6 = hp + nd.off_p6;
+    const float *v3 = hp + nd.off_v3, *p6 = hp + nd.off_p6;
     float x = 0.f, x0 = 0.f, x1 = 0.f;
-    if (lane < HW) {
-        const int y_ = lane / W, x_ = lane % W;
-        const int hs = (y_ + 1) * RS + (x_ + 1);
-        const float *xp = (const float *)(X + hs * SB);
-        float av = v3[0], a0 = p6[0], a1 = p6[1];
-        if (R_eff == 0) { // no tower: the first conv's output is still in its three planes
-            const unsigned short *hpix = (const unsigned short *)xp;
-            const int hb = XG::swz(hs) << 1;
+    {
+        const unsigned char *whp = x3.wh;
+        const bf16x8 h1 = *(const bf16x8 *)(whp + (0 * 64 + lane) * 16), h2 = *(const bf16x8 *)(whp + (1 * 64 + lane) * 16),
+                     h3 = *(const bf16x8 *)(whp + (2 * 64 + lane) * 16);
+        const f32x4 hb = g == 0 ? f32x4{v3[0], p6[0], p6[1], 0.f} : f32x4{0.f, 0.f, 0.f, 0.f}; // the convolutions' biases
+        bf16x8 y1[NT], y3[NT];
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const int cc = (((c >> 2) ^ hb) << 2) | (c & 3); // where channel c sits inside a plane of this slot
-                float xv = __uint_as_float((unsigned)hpix[cc] << 16) + __uint_as_float((unsigned)hpix[16 + cc] << 16) +
-                           __uint_as_float((unsigned)hpix[32 + cc] << 16);
-                av = __builtin_fmaf(xv, vk[c], av);
-                a0 = __builtin_fmaf(xv, pk[2 * c], a0);
-                a1 = __builtin_fmaf(xv, pk[2 * c + 1], a1);
-            }
-        } else {
+        for (int t = 0; t < NT; t++) {
+            y1[t] = *(const bf16x8 *)(X + aH1(t));
+            y3[t] = *(const bf16x8 *)(X + aH3(t));
+        }
 #pragma unroll
-            for (int c4 = 0; c4 < 4; c4++) {
-                f32x4 xv = *(const f32x4 *)(xp + 4 * c4);
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    int c = 4 * c4 + r;
-                    av = __builtin_fmaf(xv[r], vk[c], av);
-                    a0 = __builtin_fmaf(xv[r], pk[2 * c], a0);
-                    a1 = __builtin_fmaf(xv[r], pk[2 * c + 1], a1);
-                }
+        for (int t = 0; t < NT; t++) {
+            f32x4 a = hb;
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h3, y3[t], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h2, y1[t], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, y1[t], a, 0, 0, 0);
+            if (g == 0 && wv[t]) { // (halo columns and the other lane groups contribute exact zeros to the sums below)
+                x += fmaxf(__builtin_fmaf(a[0], v3[1], v3[2]), 0.f);
+                x0 += fmaxf(__builtin_fmaf(a[1], p6[2], p6[4]), 0.f);
+                x1 += fmaxf(__builtin_fmaf(a[2], p6[3], p6[5]), 0.f);
             }
         }
-        x = fmaxf(__builtin_fmaf(av, v3[1], v3[2]), 0.f);
-        x0 = fmaxf(__builtin_fmaf(a0, p6[2], p6[4]), 0.f);
-        x1 = fmaxf(__builtin_fmaf(a1, p6[3], p6[5]), 0.f);
     }
     NSTAMP(3);
     if constexpr (HEADS_OUT) {
@@ -673,7 +682,8 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
 #undef aC1
 #undef aC3
 #undef aO
-#undef aF
+#undef aH1
+#undef aH3
 #undef iA
 // bb_net_eval / lock-step and asynchronous-round search: one position per wave, four waves per workgroup, the packed
 // weights streamed from L2

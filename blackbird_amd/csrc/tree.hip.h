@@ -28,11 +28,12 @@
 #define BB_PREFETCH_CHILDREN 0
 #endif
 #ifndef BB_MOVE_BODY_ATTR
-#define BB_MOVE_BODY_ATTR
+#define BB_MOVE_BODY_ATTR __forceinline__ // (an out-of-line callee takes TreeDev by reference: the struct then lives in scratch and every field use is a scratch load)
 #endif
 #define NODE_EXPANDED 1
 #define NODE_TERMINAL 2
 #define NODE_CACHED 4 // terminal node whose evaluator value is stored in pad0 (Model.SampleValue's lru_cache)
+#define LEAF_RECORDED 0x40000000
 #define CHILD_NONE (-1)
 #define CHILD_TERM_BIT 0x40000000
 
@@ -82,6 +83,11 @@ struct TreeDev {
     float *root_W;
     int8_t *root_pp; // Player of the root's parent state, 0 = root has no parent
     uint32_t *path;  // [n_slots][MAXPATH]  node<<6 | player<<4 | action
+    // what the descent saw of every edge of the recorded path (persistent kernel, level-stepped tree waves): the backup is
+    // then stores only -- N + 1, W + v, Q, sum + 1, sqrt -- instead of a read-modify-write round trip per simulation
+    int32_t *path_N, *path_all; // [n_slots][MAXPATH]  child.Plays of the chosen edge, sum(ChildPlays) of its node
+    float *path_W;              // [n_slots][MAXPATH]  child.Value of the chosen edge
+    int32_t *leaf_flags;        // [n_slots] flags word of the posted leaf | LEAF_RECORDED (0: posted by a kernel that records nothing)
     // evaluator mailboxes
     void *leaf_state;       // [n_slots] packed state of the pending leaf
     uint32_t *leaf_game_id; // [n_slots]
@@ -241,7 +247,7 @@ __device__ __forceinline__ void backup_path(const TreeDev &d, int g, int lane, D
 
 // ---- phase A: apply the evaluator's answer for the pending leaf (expand + backup) -------------
 template <class G>
-__device__ void phase_apply(const TreeDev &d, int g, int lane) {
+__device__ __forceinline__ void phase_apply(const TreeDev &d, int g, int lane) {
     using Node = DenseNode<G>;
     constexpr int S = G::S, A = G::A;
     int leaf = d.pend_leaf[g];
@@ -283,12 +289,81 @@ __device__ void phase_apply(const TreeDev &d, int g, int lane) {
     if (lane == 0) d.pend_leaf[g] = -1;
 }
 
+// The same backup from what the descent recorded of every edge (TreeDev::path_N / path_W / path_all): stores only.  Nothing else
+// touches a game's tree between the descent of a simulation and its backup, so the recorded numbers ARE the memory's.
+template <class G>
+__device__ __forceinline__ void backup_path_rec(const TreeDev &d, int g, int lane, DenseNode<G> *pool, int plen, float v01, int prev) {
+    constexpr int S = G::S;
+    const float vflip = 1.0f - v01;
+    const uint32_t *path = d.path + (size_t)g * G::MAXPATH;
+    const int32_t *pN = d.path_N + (size_t)g * G::MAXPATH, *pA = d.path_all + (size_t)g * G::MAXPATH;
+    const float *pW = d.path_W + (size_t)g * G::MAXPATH;
+    for (int k = lane; k < plen; k += S) {
+        const uint32_t e = path[k];
+        const int a = e & 15, pl = (e >> 4) & 3;
+        DenseNode<G> *pn = pool + (e >> 6);
+        const int n = pN[k] + 1, all = pA[k] + 1;
+        const float w = pW[k] + ((pl == prev) ? v01 : vflip);
+        pn->N[a] = n;
+        pn->W[a] = w;
+        pn->Q[a] = __fdiv_rn(w, (float)n);
+        pn->all = all;
+        pn->sq = __dsqrt_rn(1.0 + (double)all);
+    }
+    if (lane == 0) {
+        d.root_N[g] += 1;
+        int pp = d.root_pp[g];
+        if (pp) d.root_W[g] += (pp == prev) ? v01 : vflip;
+    }
+}
+
+// phase_apply for a leaf posted with its flags word and path statistics recorded (LEAF_RECORDED): no loads from the tree at all.
+template <class G>
+__device__ __forceinline__ void phase_apply_rec(const TreeDev &d, int g, int lane) {
+    using Node = DenseNode<G>;
+    constexpr int S = G::S, A = G::A;
+    const int leaf = d.pend_leaf[g];
+    if (leaf < 0) return;
+    const int lf = d.leaf_flags[g] & ~LEAF_RECORDED;
+    Node *pool = (Node *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
+    Node *node = pool + leaf;
+    const typename G::State st = ((const typename G::State *)d.leaf_state)[g];
+    const float v = d.eval_value[g];
+    const int expand = d.pend_expand[g];
+    if (expand) { // AddChildren with evaluator priors
+        const uint32_t mask = G::legal_mask(st);
+        double x = 0.0;
+        if (lane < A) x = (double)d.eval_policy[(size_t)g * S + lane] * (double)((mask >> lane) & 1u);
+        const double tot = grp_np_sum<A, S>(x);
+        node->N[lane] = 0;
+        node->Q[lane] = 0.f;
+        node->W[lane] = 0.f;
+        node->child[lane] = CHILD_NONE;
+        node->cP[lane] = (lane < A) ? d.c_puct * __ddiv_rn(x, tot) : 0.0;
+        if (lane == 0) {
+            node->flags = lf | NODE_EXPANDED;
+            node->legal_mask = mask;
+            node->all = 0;
+            node->sq = 1.0;
+        }
+    }
+    const int player = gs_player(st), prev = gs_prev(st);
+    float v01 = (v + 1.0f) * 0.5f; // Model.SampleValue: float32 arithmetic
+    if (player != prev) v01 = 1.0f - v01;
+    if (!expand && (lf & NODE_TERMINAL) && lane == 0) { // remember a terminal leaf's value
+        node->pad0 = (double)v01;
+        node->flags = lf | NODE_CACHED;
+    }
+    backup_path_rec<G>(d, g, lane, pool, d.path_len[g], v01, prev);
+    if (lane == 0) d.pend_leaf[g] = -1;
+}
+
 // allocate + initialise a child node (lane 0 writes).  nn = the slot's allocation cursor (register copy).
 // Returns the child word (index | TERM bit) or CHILD_NONE when the pool is exhausted.
 template <class G>
 __device__ __forceinline__ int create_child(const TreeDev &d, int g, DenseNode<G> *pool, DenseNode<G> *parent,
                                             const typename G::State &pst, int a, int lane, int &nn,
-                                            typename G::State &st2, bool &terminal) {
+                                            typename G::State &st2, bool &terminal, int *flags_out = nullptr) {
     int idx = nn;
     st2 = pst;
     G::apply(st2, a);
@@ -297,10 +372,12 @@ __device__ __forceinline__ int create_child(const TreeDev &d, int g, DenseNode<G
     if (idx >= d.node_cap) return CHILD_NONE;
     int word = idx | (terminal ? CHILD_TERM_BIT : 0);
     nn = idx + 1;
+    const int cflags = (terminal ? (NODE_TERMINAL | ((w + 1) << 8)) : 0) | (gs_player(st2) << 4);
+    if (flags_out) *flags_out = cflags;
     if (lane == 0) {
         DenseNode<G> *c = pool + idx;
         c->st = st2;
-        c->flags = (terminal ? (NODE_TERMINAL | ((w + 1) << 8)) : 0) | (gs_player(st2) << 4);
+        c->flags = cflags;
         c->legal_mask = 0;
         c->all = 0;
         c->serial = idx;
@@ -432,6 +509,7 @@ __device__ void phase_select(const TreeDev &d, int g, int lane) {
         d.leaf_game_id[g] = d.first_game_id + (uint32_t)d.game_lid[g];
         d.leaf_serial[g] = cur;
         d.pend_leaf[g] = cur;
+        if (d.leaf_flags) d.leaf_flags[g] = 0;
         d.pend_expand[g] = expand;
         d.path_len[g] = depth;
         d.sims_left[g] -= 1;
@@ -488,7 +566,7 @@ __global__ void __launch_bounds__(256) k_tree_apply(TreeDev d) {
 // ---- root statistics + move choice -------------------------------------------------------------
 // returns the chosen action (same on every lane) or -4 (NaN probabilities) / -3 (no tree)
 template <class G>
-__device__ int choose_move(const TreeDev &d, int g, int lane, double temp, double u, int &total, int &Ni_out,
+__device__ __forceinline__ int choose_move(const TreeDev &d, int g, int lane, double temp, double u, int &total, int &Ni_out,
                            float &Wi_out) {
     using Node = DenseNode<G>;
     constexpr int S = G::S, A = G::A;
@@ -569,7 +647,7 @@ __global__ void __launch_bounds__(256) k_sample(TreeDev d, double temp) {
 
 // _moveRoot by action.  Lane-0 state updates; all lanes of the group call it.
 template <class G>
-__device__ void advance_root(const TreeDev &d, int g, int lane, int a, typename G::State &new_st) {
+__device__ __forceinline__ void advance_root(const TreeDev &d, int g, int lane, int a, typename G::State &new_st) {
     using Node = DenseNode<G>;
     Node *pool = (Node *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     Node *node = pool + d.root[g];
@@ -652,6 +730,7 @@ __device__ __forceinline__ void reset_slot(const TreeDev &d, int g, int lid, con
     d.path_len[g] = 0;
     d.sim_serial[g] = 0;
     d.game_lid[g] = lid;
+    if (d.leaf_flags) d.leaf_flags[g] = 0;
 }
 
 template <class G>
@@ -699,7 +778,7 @@ __device__ __forceinline__ uint8_t *example_ptr(const TreeDev &d, int lid, int p
 }
 
 template <class G>
-__device__ void write_example(const TreeDev &d, int lid, int ply, const typename G::State &st, int lane, int Ni,
+__device__ __forceinline__ void write_example(const TreeDev &d, int lid, int ply, const typename G::State &st, int lane, int Ni,
                               int total, uint32_t gid) {
     uint8_t *p = example_ptr<G>(d, lid, ply);
     if (lane == 0) {
@@ -802,7 +881,9 @@ __global__ void __launch_bounds__(256) k_selfplay_move(TreeDev d) {
 //   a descent that outlives the budget is parked (resume_cur/resume_depth) and continues next launch.
 // Per game the sequence of simulations is exactly the sequential one, so results do not depend on the
 // schedule (tests/test_gpu_mcts.py: self-play == oracle, example by example).
-template <class G>
+// REC (persistent kernel with the recorded-path arrays in LDS): the descent notes N, W and sum(N) of every edge it takes and the
+// backups are stores only (backup_path_rec / phase_apply_rec).
+template <class G, bool REC = false>
 __device__ bool async_game(const TreeDev &d, int g, int lane
 #ifdef BB_STAMPS_LIGHT
                            , int &g_light_loop, int &g_light_levels, int &g_light_load, int &g_light_puct
@@ -819,7 +900,8 @@ __device__ bool async_game(const TreeDev &d, int g, int lane
     int lt_in = (int)clock64(), lt_loop = 0, ln_levels = 0, lt_create = 0, lt_puct = 0;
 #endif
     if (d.pend_leaf[g] >= 0) {
-        phase_apply<G>(d, g, lane);
+        if (REC && (d.leaf_flags[g] & LEAF_RECORDED)) phase_apply_rec<G>(d, g, lane);
+        else phase_apply<G>(d, g, lane);
         if (lane == 0) d.sims_left[g] -= 1;
         __threadfence_block();
     }
@@ -884,6 +966,12 @@ __device__ bool async_game(const TreeDev &d, int g, int lane
             double cPi = node->cP[lane];
             int ci = node->child[lane];
             double cached = node->pad0;
+            float Wi = 0.f;
+            int all_l = 0;
+            if (REC) {
+                Wi = node->W[lane];
+                all_l = node->all;
+            }
             asm volatile("" ::"v"(flags_l), "v"(mask), "v"(sq), "v"(Ni), "v"(Qi), "v"(cPi), "v"(ci), "v"(pf_touch)); // (the previous level's touch is older than these loads)
 #if defined(BB_STAMPS_DEEP) && defined(BB_STAMPS_PERLEVEL)
             st_load += clock64() - ts0;
@@ -907,7 +995,8 @@ __device__ bool async_game(const TreeDev &d, int g, int lane
                         int lt_k = (int)clock64();
 #endif
                         __threadfence_block(); // path stores of this descent
-                        backup_path<G>(d, g, lane, pool, depth, v01, gs_prev(st));
+                        if (REC) backup_path_rec<G>(d, g, lane, pool, depth, v01, gs_prev(st));
+                        else backup_path<G>(d, g, lane, pool, depth, v01, gs_prev(st));
                         if (lane == 0) d.sims_left[g] -= 1;
                         __threadfence_block();
 #ifdef BB_STAMPS_LIGHT2
@@ -950,13 +1039,20 @@ __device__ bool async_game(const TreeDev &d, int g, int lane
             lt_puct += (int)clock64() - lt_b;
 #endif
             if (lane == 0) path[depth] = ((uint32_t)cur << 6) | ((uint32_t)((flags >> 4) & 3) << 4) | (uint32_t)a;
+            if (REC) { // what the backup of this edge will start from
+                if (lane == 0) d.path_all[(size_t)g * G::MAXPATH + depth] = all_l;
+                if (lane == a) {
+                    d.path_N[(size_t)g * G::MAXPATH + depth] = Ni;
+                    d.path_W[(size_t)g * G::MAXPATH + depth] = Wi;
+                }
+            }
             if (child == CHILD_NONE) {
                 typename G::State st2;
                 bool terminal;
 #ifdef BB_STAMPS_LIGHT2
                 int lt_c = (int)clock64();
 #endif
-                child = create_child<G>(d, g, pool, node, st, a, lane, nn, st2, terminal);
+                child = create_child<G>(d, g, pool, node, st, a, lane, nn, st2, terminal, &flags);
 #ifdef BB_STAMPS_LIGHT2
                 asm volatile("" ::"v"(child));
                 lt_create += (int)clock64() - lt_c;
@@ -964,8 +1060,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane
                 if (child == CHILD_NONE) { fl |= F_OVERFLOW | F_LEAF; break; }
                 // the node just created is the leaf of this descent (never expanded, never cached): finish here instead of
                 // going round the loop once more to read back the row that was written a moment ago
-                st = st2;
-                flags = (terminal ? NODE_TERMINAL : 0) | (gs_player(st2) << 4);
+                st = st2; // (flags = the word create_child stored for the new node)
                 depth++;
                 cur = child & ~CHILD_TERM_BIT;
                 fl |= F_LEAF | (terminal ? F_TERM : F_EXPAND);
@@ -991,6 +1086,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane
             d.leaf_game_id[g] = d.first_game_id + (uint32_t)d.game_lid[g];
             d.leaf_serial[g] = cur;
             d.pend_leaf[g] = cur;
+            if (d.leaf_flags) d.leaf_flags[g] = REC ? (flags | LEAF_RECORDED) : 0;
             d.pend_expand[g] = (fl & F_EXPAND) ? 1 : 0;
             d.path_len[g] = depth;
             d.sim_serial[g] += 1;
