@@ -12,16 +12,21 @@ Workloads (--workload):
   dc (configs[3]): DragonChess, 400 simulations/move, 1024 concurrent games, R4/F16/D16 on 17 planes, 4032-wide policy
      head, ply cap 512 (the reference has no draw rule: documented deviation).
 
-A "step" is `sims` tree visits per concurrent game, handed out by the persistent self-play kernel from one pool per launch
-(or `sims` x (tree kernel + network kernel) + one move kernel in the launch-per-round modes).  A visit completes at least
-one simulation (more when it meets terminal leaves whose value is already known), so a step is about one ply of every
-game; `plies_per_step` says how many it was.  Finished games hand their slot to a fresh game, so the batch stays full;
-`value` is games completed inside the timed region / wall time (whole job, all ranks).  The timed region = the K steps +
-the extraction to the host of the example records of as many finished games as it produced (SURVEY.md 8d counts example
-extraction in the metric).  Before warm-up the games are de-synchronised by an untimed prefill at few simulations per
-move (otherwise all games would start and finish in lock-step and a short timed window would see no completions);
-`games_per_sec_steady` = plies/s / mean plies of the games that finished in the timed region is the renewal-rate
-estimate that does not depend on where the window falls.
+A "step" is `sims` tree visits per concurrent game, handed out by the persistent self-play kernel from the launch's visit
+pools (or `sims` x (tree kernel + network kernel) + one move kernel in the launch-per-round modes).  A visit completes at
+least one simulation (more when it meets terminal leaves whose value is already known), so a step is about one ply of every
+game; `plies_per_step` says how many it was.  Finished games hand their slot to a fresh game, so the batch stays full.
+
+Untimed, before the W warm-up steps: a PREFILL at few simulations per move that de-synchronises the games (otherwise all
+games would start and finish in lock-step) and a SETTLE phase of max_plies steps at full strength -- after it no game that was
+begun during the prefill is left, so every game that finishes inside the timed region was played at `sims` simulations
+per move from its first move to its last (`full_strength_fraction` = 1) and the window is a steady-state sample.
+Timed: the K steps as >= 3 back-to-back launches (HIP events on the engine's stream around each: `roofline.launch_ms_*`) + the
+extraction to the host of the example records of exactly the games that finished inside the region (found by the change
+of their `done` words).  `value` = those games / wall time (whole job, all ranks); `games_per_sec_steady` = plies/s / their
+mean length is the renewal-rate estimate of the same thing.  `api_games_per_sec` is what a caller of the drop-in
+`Blackbird.GenerateTrainingSamples(model, 8192, 1.0)` gets end to end: protobuf blobs + one PutGames per game into sqlite,
+host work overlapped with the GPU, the batch's start and tail included (Blackbird.py:219-268).
 
 N > 1: one process per GPU (torch.distributed, backend nccl == RCCL), disjoint game-id/RNG streams per rank, no
 collective in the data path; the (s, pi, z) examples are all-gathered once after timing, device to device
@@ -53,11 +58,11 @@ PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec (6290 measured 
 WORKLOADS = {
     # game, H*W, planes, actions, blocks, filters, sims, slots, max_plies, prefill (plies, sims/move), steps, warmup, BASELINE configs index
     "c2": dict(game=_lib.GAME_CONNECT4, name="Connect4 7x6", hw=42, C=3, A=7, blocks=4, filters=16, sims=800, slots=4096,
-               max_plies=42, prefill=(64, 32), steps=32, warmup=8, cfg=1, min_game_plies=7),
+               max_plies=42, prefill=(64, 32), settle=44, steps=32, warmup=8, cfg=1, min_game_plies=7),
     "c5": dict(game=_lib.GAME_CONNECT4, name="Connect4 7x6", hw=42, C=3, A=7, blocks=20, filters=256, sims=800, slots=4096,
-               max_plies=42, prefill=(64, 32), steps=32, warmup=8, cfg=4, min_game_plies=7),
+               max_plies=42, prefill=(64, 32), settle=0, steps=32, warmup=8, cfg=4, min_game_plies=7),
     "dc": dict(game=_lib.GAME_DRAGONCHESS, name="DragonChess 8x8", hw=64, C=17, A=4032, blocks=4, filters=16, sims=400,
-               slots=1024, max_plies=512, prefill=(96, 8), steps=32, warmup=4, cfg=3, min_game_plies=3),
+               slots=1024, max_plies=512, prefill=(96, 8), settle=0, steps=32, warmup=4, cfg=3, min_game_plies=3),
 }
 
 
@@ -166,19 +171,63 @@ def cpu_baseline(key, w, flat, gpu_mean_plies, budget_s=20.0):
     return out
 
 
-def pmc_traffic_bytes_per_second(key):
-    """HBM bytes/s of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
-    separate runs; profiles/README.md).  FETCH_SIZE is used as reported: the tree side reads scattered 4-32 B fields, not
-    the wide streams for which MI355X_MICROARCH.md gives the x2 correction, so the read side is a lower bound."""
-    for name in {"c2": ("r02_queue_pmc_summary.json", "r01_v6_queue_pmc_summary.json"),
-                 "dc": ("r02_dc_pmc_summary.json",), "c5": ()}[key]:
+def profile_figures(key):
+    """Per-evaluation figures of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (separate passes,
+    counters only: tools/profile_round.sh): bf16 MFMA operations issued (SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 FLOP) and HBM bytes
+    (FETCH_SIZE as reported + WRITE_SIZE: the tree side reads scattered 4-32 B fields, not the wide streams for which
+    MI355X_MICROARCH.md gives the x2 correction, so the read side is a lower bound).  They are measurements of ANOTHER run of
+    the same kernel: the line labels them `from_profile` with the commit they were taken at."""
+    for name in {"c2": ("r03_queue_pmc_summary.json",), "dc": ("r03_dc_pmc_summary.json",), "c5": ()}[key]:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 p = json.load(f)
-            return (p["hbm_read_GBps_raw"] + p["hbm_write_GBps"]) * 1e9, name
-        except (OSError, KeyError, ValueError):
+            ev = float(p["evals_in_dispatch"])
+            return {"file": "profiles/" + name, "commit": p.get("commit"),
+                    "mfma_bf16_flop_per_eval": p["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512.0 / ev,
+                    "hbm_bytes_per_eval": (p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0 / ev}
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
             continue
-    return None, None
+    return None
+
+
+def api_games_per_sec(n_games=8192, sims=800):
+    """Blackbird.GenerateTrainingSamples(model, n_games, 1.0) end to end on the drop-in API (Blackbird.py:219-268): engine +
+    example extraction + state.proto blobs + one Conn.PutGames per game into a fresh sqlite database."""
+    import tempfile
+    from blackbird_amd import Blackbird, Connect4
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp(prefix="bb_bench_api_"))
+    try:
+        net = {"blocks": 4, "filters": 16, "eval": {"dense": 16}, "hasTeacher": False,
+               "policy": {"dirichlet": {"alpha": 0.2, "epsilon": 0.3}}, "training": {"optimizer": "adam"}}
+        model = Blackbird.Model(Connect4.BoardState, "bench", {"explorationRate": 0.85, "playLimit": sims}, net)
+        model._selfplay_engine(n_games)                      # engine creation + weight upload: one-time, untimed (SURVEY 8d)
+        Blackbird.GenerateTrainingSamples(model, 64, 1.0)    # warm the code paths
+        t0 = time.perf_counter()
+        Blackbird.GenerateTrainingSamples(model, n_games, 1.0)
+        dt = time.perf_counter() - t0
+        stored = len(model.Conn.GetGames(model.Name, model.Version))
+        # the same batch on the engine alone (no blobs, no sqlite): a finite batch cannot finish before its longest slot has
+        # played its games one after another -- n_games / slots games of ~30 plies at ~25 ms per ply -- whatever the host does
+        eng = model._batch_engine
+        eng.set_rng_stream(12345, 0)
+        t1 = time.perf_counter()
+        eng.selfplay_begin(n_games, 1.0)
+        while not eng.selfplay_done()[0]:
+            eng.selfplay_step(4)
+        dt_eng = time.perf_counter() - t1
+        eng.close()
+        model._batch_engine = None
+        return {"value": n_games / dt, "unit": "games/s", "games": n_games, "wall_s": dt, "examples_stored": stored,
+                "engine_only_same_batch_games_per_sec": n_games / dt_eng, "engine_only_same_batch_wall_s": dt_eng,
+                "api_over_engine_same_batch": dt_eng / dt,
+                "what": "Blackbird.GenerateTrainingSamples(model, %d, 1.0): %d concurrent games with slot refill, blobs + PutGames "
+                        "into sqlite, host sink overlapped with the GPU; start-up and tail of the batch included.  "
+                        "engine_only_same_batch = the same finite batch without the host sink: its games/s is below the "
+                        "steady-state `value` because a batch ends with its longest chain of games (the tail), not because of host work"
+                        % (n_games, min(n_games, 4096))}
+    finally:
+        os.chdir(cwd)
 
 
 def main():
@@ -189,7 +238,10 @@ def main():
     ap.add_argument("--slots", type=int, default=None)
     ap.add_argument("--sims", type=int, default=None)
     ap.add_argument("--prefill", type=int, default=None, help="untimed de-synchronisation plies at few sims/move")
+    ap.add_argument("--settle", type=int, default=None, help="untimed full-strength steps after the prefill (default: max_plies + 2 for c2)")
+    ap.add_argument("--launches", type=int, default=3, help="launches the K timed steps are split into (>= 3 by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the GenerateTrainingSamples end-to-end leg (c2, one GPU)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 = BASELINE configs[1] (default, the headline); c5 = configs[4]'s 20x256 network on one GPU "
                          "(use --steps 1 --warmup 0 --prefill 1); dc = configs[3] DragonChess 1024 games x 400 sims")
@@ -200,6 +252,7 @@ def main():
     slots = w["slots"] if args.slots is None else args.slots
     sims = w["sims"] if args.sims is None else args.sims
     prefill = w["prefill"][0] if args.prefill is None else args.prefill
+    settle = w["settle"] if args.settle is None else args.settle
     w["sims"] = sims
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -237,12 +290,12 @@ def main():
     flat = W.flatten(W.init_weights(w["C"], w["filters"], w["blocks"], 16, w["A"], seed=0))
     fpe = flops_per_eval(w)
     assert args.workload != "c2" or fpe == FLOPS_PER_EVAL_C2
-    total_plies = prefill + Wm + K + 2
+    total_plies = prefill + settle + Wm + K + 2
     # every slot finishes at most one game per `min_game_plies` plies (a visit can complete several simulations, so a
     # step can be more than one ply: x2 head-room)
     max_games = slots * (2 * total_plies // w["min_game_plies"] + 2)
     if args.workload == "dc":
-        max_games = slots * 8  # DragonChess games last tens to hundreds of plies (mean ~80 under weak play)
+        max_games = slots * (8 + settle // 32)  # DragonChess games last tens to hundreds of plies (mean ~80 under weak play)
     from blackbird_amd import dist as bdist
     first_id, seed = bdist.shard(rank, 1234)
     eng = _lib.Engine(game, n_slots=slots, sims_per_move=sims, evaluator=_lib.EVAL_NET, c_puct=0.85,
@@ -254,49 +307,58 @@ def main():
         eng.set_sims_per_move(min(w["prefill"][1], sims))
         eng.selfplay_step(prefill)
         eng.set_sims_per_move(sims)
+    if settle > 0:
+        eng.selfplay_step(settle)   # untimed, full strength: afterwards every game in flight was begun at `sims` simulations per move
     if Wm > 0:
         eng.selfplay_step(Wm)
     eng.synchronize()
     eng.reset_counters()
+    hdr0 = eng.selfplay_headers(0, max_games)
     eng.timing_enable(97)  # HIP events (engine stream) around every persistent launch / every 97th network launch
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    n_launch = max(1, min(args.launches, K))
+    parts = [K // n_launch + (1 if i < K % n_launch else 0) for i in range(n_launch)]
     barrier()
     eng.synchronize()
     t0 = time.perf_counter()
-    eng.selfplay_step(K)
+    for part in parts:          # exactly K steps, as back-to-back launches on the engine's stream
+        eng.selfplay_step(part)
     eng.synchronize()
-    # example extraction belongs to the metric ("all kernels + host orchestration + example extraction")
-    # -- as many finished games as the timed region produced (the oldest ids: complete records) come back to the host
+    # example extraction belongs to the metric ("all kernels + host orchestration + example extraction"):
+    # the records of exactly the games that finished inside the timed region come back to the host
     tf = time.perf_counter()
     cnt = eng.counters()
-    rec_t, _offs_t, _win_t = eng.fetch_examples(0, max(int(cnt["games_finished"]), 1))
+    hdr1 = eng.selfplay_headers(0, max_games)
+    new_ids = np.nonzero((hdr1[:, 3] != 0) & (hdr0[:, 3] == 0))[0]
+    if len(new_ids):
+        rec_t, offs_t, _win_t = eng.fetch_games(new_ids, int(hdr1[new_ids, 0].sum()))
+    else:
+        rec_t, offs_t = np.zeros(0, dtype=_lib.example_dtype(game)), np.zeros(1, dtype=np.int32)
     fetch_s = time.perf_counter() - tf
     barrier()
     dt = time.perf_counter() - t0
 
     net_ms, net_min_ms, net_n = eng.timing_read()
     games, nsims, plies = cnt["games_finished"], cnt["sims"], cnt["plies"]
-    # game lengths of what finished inside the timed region (game ids are dealt in order, so "finished" is not a prefix:
-    # read every header once)
-    rec_all, offs_all, win_all = eng.fetch_examples(0, max_games)
-    lens = np.diff(offs_all)
-    fin = np.nonzero(lens > 0)[0]
-    # records of games that were finished when the timed region began carry nothing new: the timed region's games are
-    # those whose LAST record's total-visit count belongs to a full-strength search or that finished after the snapshot;
-    # the length statistic simply uses every finished game of the run that started at full strength
-    first_tot = rec_all["total"][offs_all[fin]] if len(fin) else np.zeros(0)
-    full = fin[first_tot >= sims - 1] if len(fin) else fin
-    mean_plies_all = float((lens[fin] - 1).mean()) if len(fin) else 0.0
-    # games that started at full strength AND finished inside a short run are the short ones: only trust their mean when
-    # the run is long enough for typical games to be among them
-    mean_plies_full = float((lens[full] - 1).mean()) if (len(full) >= 200 and total_plies - prefill >= w["max_plies"]) else 0.0
+    assert games == len(new_ids), (games, len(new_ids))   # the counter and the headers tell the same story
+    # the games of the timed region: their lengths, and whether they were played at full strength from the first move (the first
+    # record's visit total is playLimit - 1 on a fresh root)
+    lens_new = hdr1[new_ids, 2].astype(np.float64) if len(new_ids) else np.zeros(0)
+    first_tot = rec_t["total"][offs_t[:-1]] if len(new_ids) else np.zeros(0)
+    full = first_tot >= sims - 1
+    mean_plies_all = float(lens_new.mean()) if len(new_ids) else 0.0
+    mean_plies_full = float(lens_new[full].mean()) if full.sum() >= 100 else 0.0
+    full_fraction = float(full.mean()) if len(new_ids) else 0.0
+    overflow_any = cnt["overflow"]
     if dist is not None:
         dev = f"cuda:{local}" if backend == "nccl" else None
-        (games, nsims, plies), (dt,) = bdist.reduce_totals([games, nsims, plies], [dt], device=dev)
+        (games, nsims, plies, overflow_any), (dt,) = bdist.reduce_totals([games, nsims, plies, cnt["overflow"]], [dt], device=dev)
+        # a pool ran out or a launch aborted on SOME rank: no rank's games are the specified workload any more
+
         # epoch-end exchange: all-gather the finished games' (s, pi, z) records
         import torch
         tg = time.perf_counter()
@@ -305,6 +367,7 @@ def main():
             torch.cuda.synchronize()
             n_examples_all = int(allrec.shape[0])
         else:
+            rec_all, _o, _w = eng.fetch_examples(0, max_games)
             n_examples_all = int(len(bdist.allgather_records(rec_all)))
         allgather_s = time.perf_counter() - tg
     else:
@@ -344,12 +407,18 @@ def main():
         a_c = 7.0 if gname == "Connect4" else 14.6   # DragonChess: mean legal count of SURVEY.md 6 [probe]
         b_sim = tree_bytes_per_sim(w, mean_depth, a_c)
         tree_gbps = b_sim * sims_per_launch / (net_ms * 1e-3) / 1e9 if net_ms > 0 else 0.0
-        traffic_rate, traffic_src = pmc_traffic_bytes_per_second(args.workload)
+        prof = profile_figures(args.workload)
         # mean game length for the steady-state estimate and the CPU extrapolation: observed, or (no game finished in this
         # run) the value default runs of that workload observe
         mean_len = mean_plies_full or mean_plies_all or {"c2": 28.0, "c5": 28.0, "dc": 60.0}[args.workload]
+        dc = args.workload == "dc"
+        games_rate = games / dt
         out = {
-            "metric": "selfplay_games_per_sec", "value": games / dt, "unit": "games/s",
+            # DragonChess games last up to the 512-ply cap: a window of tens of steps finishes mostly games that were begun in the
+            # weak-play prefill, so the headline there is plies/s (node_evals_per_sec beside it) and games/s is only quoted from
+            # games played at full strength throughout (--settle 512), else null
+            "metric": "selfplay_plies_per_sec" if dc else "selfplay_games_per_sec",
+            "value": (plies / dt) if dc else games_rate, "unit": "plies/s" if dc else "games/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": dt / max(K, 1) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (float32 operands split exactly into 3 bf16 values, 6 bf16 MFMA products each, f32 accumulate)" if x3 else "f32",
@@ -362,13 +431,18 @@ def main():
                        "step": "%d tree visits of every game (>= one ply each; see plies_per_step)" % sims,
                        "launch_structure": ["lockstep", "async-rounds", "retired", "persistent-queue", "retired", "wave-per-game"][mode],
                        "prefill": "%d plies at %d sims/move (untimed)" % (prefill, min(w["prefill"][1], sims)),
+                       "settle": "%d steps at %d sims/move (untimed): no game from the prefill is left in flight" % (settle, sims),
+                       "timed_launches": parts,
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
             "node_evals_per_sec": nsims / dt, "net_evals_per_sec_rank0": cnt["evals"] / dt, "plies_per_sec": plies / dt,
+            "evals_timed_rank0": cnt["evals"], "sims_timed": nsims,
             "plies_per_step": plies / max(K, 1) / (slots * world),
-            "games_finished": games, "mean_plies_finished_games": mean_plies_all,
-            "mean_plies_games_started_at_full_sims": mean_plies_full,
+            "games_finished": games, "games_per_sec_window": games_rate, "mean_plies_finished_games": mean_plies_all,
+            "mean_plies_games_started_at_full_sims": mean_plies_full, "full_strength_fraction": full_fraction,
+            "games_per_sec_full_strength": ((plies / dt) / mean_plies_full) if mean_plies_full > 0 else None,
             "games_per_sec_steady": (plies / dt) / mean_len if mean_len > 0 else None, "mean_plies_used": mean_len,
             "examples_fetched": int(len(rec_t)), "examples_fetch_s": fetch_s,
+            "examples_fetch": "records of the games whose `done` word turned on inside the timed region (bb_examples_fetch_games)",
             "terminal_leaf_fraction": cnt["terminal_leaves"] / max(cnt["sims"], 1),
             "mean_leaf_depth": mean_depth, "overflow": cnt["overflow"],
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved,
@@ -376,11 +450,15 @@ def main():
                          "peak_note": ("bf16 MFMA dense peak 2500 / 6 products per float32 product; against the float32 MFMA "
                                        "peak (157.3) the same algorithmic rate is %.3f" % (achieved / PEAK_F32_MFMA_TFLOPS))
                                       if x3 else "float32 MFMA dense peak",
-                         "bf16_tflops_issued": (achieved * X3_PRODUCTS * 48.0 / 42.0) if (form == 2 and gname == "Connect4") else None,
-                         "traffic": (traffic_rate * net_ms * 1e-3) if (mode >= 2 and traffic_rate) else None,
-                         "traffic_note": ("HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) rate from profiles/%s x this "
-                                          "launch's duration" % traffic_src) if traffic_src else "no PMC pass committed for this workload",
-                         "launch_ms_mean": net_ms, "launch_ms_min": net_min_ms,
+                         # counters of ANOTHER run of this kernel (rocprofv3 --pmc passes committed under profiles/), per
+                         # evaluation, scaled by this launch's evaluations -- never a measurement of the timed run itself
+                         "bf16_tflops_issued": (prof["mfma_bf16_flop_per_eval"] * flops_per_launch / fpe / (net_ms * 1e-3) / 1e12)
+                                               if (prof and x3 and mode >= 2 and net_ms > 0) else None,
+                         "traffic": (prof["hbm_bytes_per_eval"] * flops_per_launch / fpe) if (prof and mode >= 2) else None,
+                         "traffic_source": ("from_profile: %s (commit %s): SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 FLOP and (FETCH_SIZE + "
+                                            "WRITE_SIZE) bytes per evaluation x this launch's evaluations" % (prof["file"], prof["commit"]))
+                                           if prof else "no PMC pass committed for this workload",
+                         "launch_ms_mean": net_ms, "launch_ms_min": net_min_ms, "launch_ms_total": net_ms * net_n,
                          "launches_timed": net_n, "flops_per_launch": flops_per_launch, "flops_per_eval": fpe,
                          "tree_side": {"bound": "hbm", "bytes_per_sim": b_sim, "achieved": tree_gbps, "peak": PEAK_HBM_GBPS,
                                        "unit": "GB/s", "frac": tree_gbps / PEAK_HBM_GBPS,
@@ -388,19 +466,28 @@ def main():
                                                "pointer chasing, reported for completeness"}},
         }
         if allgather_s is not None:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["collective_backend"] = backend + (" (RCCL over xGMI)" if backend == "nccl" else "")
             out["examples_allgather_s"] = allgather_s
             out["examples_gathered"] = n_examples_all
             out["examples_allgather_path"] = "device (engine store -> RCCL)" if backend == "nccl" else "host (gloo rehearsal)"
-        if cnt["overflow"]:
-            # a pool ran out or a persistent launch aborted: the games are not the specified workload any more
+        if overflow_any:
+            # a pool ran out or a persistent launch aborted (on any rank): the games are not the specified workload any more
             out["value"] = None
-            out["error"] = "overflow counter is %d: result invalid" % cnt["overflow"]
+            out["error"] = "overflow counter is %d (summed over ranks): result invalid" % overflow_any
             rc = 1
         elif world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, w, flat, mean_len)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] else None
-        print(json.dumps(out))
+            gps = games_rate if not dc else (out["games_per_sec_full_strength"] or out["games_per_sec_steady"])
+            out["gpu_over_cpu"] = gps / out["cpu_baseline"]["value"] if (gps and out["cpu_baseline"]["value"]) else None
     eng.close()
+    if rank == 0:
+        if rc == 0 and world == 1 and args.workload == "c2" and not args.no_api:
+            api = api_games_per_sec(sims=sims)   # (the engine above is closed: the drop-in model creates its own)
+            out["api_games_per_sec"] = api["value"]
+            out["api"] = api
+            out["api_over_engine"] = api["value"] / games_rate if games_rate else None
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
     sys.exit(rc)

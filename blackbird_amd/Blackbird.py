@@ -165,11 +165,6 @@ def GenerateTrainingSamples(model, nGames, temp):
     model._games_played = (model._games_played + nGames) % (1 << 31)
     eng.reset_counters()
     eng.selfplay_begin(nGames, temp)
-    while not eng.selfplay_done()[0]:
-        eng.selfplay_step(8)  # (a persistent launch per call: few long launches beat many short ones, each has a tail)
-        if eng.counters()['overflow']:  # pool exhausted, a parked slot or an aborted launch: the games would never finish
-            raise _lib.BlackbirdHipError('self-play stopped: a search tree outgrew its node pool or a launch was aborted')
-    rec, offs, _win = eng.fetch_examples(0, nGames)
     # (s, pi, z) of every example in bulk: AsInputArray planes by one bb_game_encode call per chunk, pi = visits / total in
     # float64 exactly as Node.ChildProbability forms it, wire blobs assembled as one byte matrix -- then one PutGames per
     # game, as the reference issues them (Blackbird.py:267), inside a single sqlite transaction
@@ -190,21 +185,49 @@ def GenerateTrainingSamples(model, nGames, temp):
         return proto_wire.encode_states_batch(r['z'].astype(np.float32), pi, planes[:, None])
 
     per = max(1, (1 << 22) // gi.A)  # chunks of whole games, about 32 MB of pi at a time (DragonChess: 4032 float64 per example)
-    deferred = getattr(model.Conn, 'Deferred', None)
-    ctx = deferred() if deferred is not None else None
-    if ctx is not None:
-        ctx.__enter__()
-    try:
-        g = 0
-        while g < nGames:
+
+    def sink(rec, offs):
+        """Blobs + one PutGames per game for a batch of finished games (records compacted in game order)."""
+        n, g = len(offs) - 1, 0
+        while g < n:
             h = g + 1
-            while h < nGames and offs[h + 1] - offs[g] <= per:
+            while h < n and offs[h + 1] - offs[g] <= per:
                 h += 1
             blobs = blobs_of(rec[offs[g]:offs[h]])
             for k in range(g, h):
                 model.Conn.PutGames(model.Name, model.Version, game_cls.GameType,
                                     blobs[offs[k] - offs[g]:offs[k + 1] - offs[g]])
             g = h
+
+    # The host side runs BESIDE the GPU: while a launch plays on, the games that finished during the previous ones are fetched
+    # (compacted on the device, one copy), serialised and stored.  The engine refills a finished game's slot with the next game
+    # id by itself, so nGames may exceed the slot count.  (Round 2 serialised everything after the last game had ended: the
+    # caller saw 60 % of the engine's games/s.)
+    deferred = getattr(model.Conn, 'Deferred', None)
+    ctx = deferred() if deferred is not None else None
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        seen = np.zeros(nGames, dtype=bool)
+        pending = None
+        steps = 4  # plies' worth of search per launch: short enough that the last launches' games do not pile up at the end
+        while True:
+            eng.selfplay_step(steps)            # asynchronous: returns as soon as the launch is queued
+            if pending is not None:
+                sink(*pending)                  # ... and this runs while it plays
+                pending = None
+            hdr = eng.selfplay_headers(0, nGames)   # (waits for the launch)
+            if eng.counters()['overflow']:  # pool exhausted, a parked slot or an aborted launch: the games would never finish
+                raise _lib.BlackbirdHipError('self-play stopped: a search tree outgrew its node pool or a launch was aborted')
+            new = np.nonzero((hdr[:, 3] != 0) & ~seen)[0]
+            if len(new):
+                seen[new] = True
+                rec, offs, _win = eng.fetch_games(new, int(hdr[new, 0].sum()))
+                pending = (rec, offs)
+            if seen.all():
+                break
+        if pending is not None:
+            sink(*pending)
     finally:
         if ctx is not None:
             ctx.__exit__(None, None, None)

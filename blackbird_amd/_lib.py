@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libblackbird_hip.so")
 GAME_CONNECT4, GAME_TICTACTOE, GAME_DRAGONCHESS = 0, 1, 2
 MCTS_DYNAMIC, MCTS_FIXED = 0, 1
 EVAL_HASH, EVAL_NET, EVAL_ROLLOUT = 0, 1, 2
+NET_FORM_AUTO, NET_FORM_F32, NET_FORM_SPLIT = 0, 1, 2   # bb_config.net_form
+LAUNCH_AUTO, LAUNCH_LOCKSTEP, LAUNCH_ROUNDS = 0, 1, 2    # bb_config.launch
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_NAN, ERR_CAPACITY, ERR_WEIGHTS = 0, -1, -2, -3, -4, -5, -6
 
 EXPORTS = (
@@ -22,7 +24,7 @@ EXPORTS = (
     "bb_game_encode", "bb_game_initial", "bb_create", "bb_destroy", "bb_load_weights", "bb_get_counters",
     "bb_reset_counters", "bb_synchronize", "bb_set_sims_per_move", "bb_timing_enable", "bb_timing_read", "bb_timing_net", "bb_selfplay_mode", "bb_net_form", "bb_net_eval", "bb_hash_eval", "bb_set_roots", "bb_run_sims", "bb_run_sims_masked",
     "bb_sample_moves", "bb_move_roots", "bb_get_root_states", "bb_selfplay_begin", "bb_selfplay_step",
-    "bb_selfplay_done", "bb_examples_fetch", "bb_examples_device", "bb_net_eval_keyed", "bb_set_rng_stream", "bb_fit_slots",
+    "bb_selfplay_done", "bb_examples_fetch", "bb_examples_device", "bb_selfplay_headers", "bb_examples_fetch_games", "bb_net_eval_keyed", "bb_set_rng_stream", "bb_fit_slots",
 )
 
 
@@ -45,7 +47,8 @@ class Config(C.Structure):
                 ("evaluator", C.c_int32), ("sims_per_move", C.c_int32), ("max_plies", C.c_int32),
                 ("max_games", C.c_int32), ("c_puct", C.c_double), ("seed", C.c_uint64), ("hash_salt", C.c_uint64),
                 ("first_game_id", C.c_uint32), ("noise_on", C.c_int32), ("alpha", C.c_float), ("epsilon", C.c_float),
-                ("device", C.c_int32), ("salt_per_game", C.c_int32), ("node_capacity", C.c_int32)]
+                ("device", C.c_int32), ("salt_per_game", C.c_int32), ("node_capacity", C.c_int32),
+                ("net_form", C.c_int32), ("launch", C.c_int32), ("general_net", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -105,6 +108,8 @@ def lib():
     L.bb_selfplay_step.argtypes = [vp, ip]
     L.bb_selfplay_done.argtypes = [vp, C.POINTER(ip), C.POINTER(ip)]
     L.bb_examples_fetch.argtypes = [vp, ip, ip, vp, ip, vp, vp]
+    L.bb_selfplay_headers.argtypes = [vp, ip, ip, vp]
+    L.bb_examples_fetch_games.argtypes = [vp, ip, vp, vp, ip, vp, vp]
     L.bb_examples_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(vp)]
     for name in EXPORTS:
         if name != "bb_last_error":
@@ -278,7 +283,10 @@ class Engine:
 
     def __init__(self, game, n_slots, sims_per_move, *, mcts_kind=MCTS_DYNAMIC, max_depth=10, evaluator=EVAL_NET,
                  c_puct=0.85, max_plies=None, max_games=None, seed=1234, hash_salt=0, first_game_id=0,
-                 noise_on=False, alpha=0.2, epsilon=0.3, device=0, salt_per_game=False, node_capacity=0):
+                 noise_on=False, alpha=0.2, epsilon=0.3, device=0, salt_per_game=False, node_capacity=0,
+                 net_form=0, launch=0, general_net=False):
+        """net_form: NET_FORM_AUTO / NET_FORM_F32 / NET_FORM_SPLIT (bb_config.net_form); launch: LAUNCH_AUTO / LAUNCH_LOCKSTEP /
+        LAUNCH_ROUNDS (bb_config.launch); general_net: a 16-filter network through the launch-per-layer kernels."""
         self.game = game
         self.info = game_info(game)
         if max_plies is None:
@@ -286,7 +294,8 @@ class Engine:
         cfg = Config(game=game, n_slots=n_slots, mcts_kind=mcts_kind, max_depth=max_depth, evaluator=evaluator,
                      sims_per_move=sims_per_move, max_plies=max_plies, max_games=max_games or n_slots, c_puct=c_puct,
                      seed=seed, hash_salt=hash_salt, first_game_id=first_game_id, noise_on=int(noise_on), alpha=alpha,
-                     epsilon=epsilon, device=device, salt_per_game=int(salt_per_game), node_capacity=node_capacity)
+                     epsilon=epsilon, device=device, salt_per_game=int(salt_per_game), node_capacity=node_capacity,
+                     net_form=int(net_form), launch=int(launch), general_net=int(bool(general_net)))
         self.cfg = cfg
         self.h = C.c_void_p()
         self.n_slots = n_slots
@@ -452,6 +461,23 @@ class Engine:
         offs = np.zeros(n_games + 1, dtype=np.int32)
         win = np.zeros(n_games, dtype=np.int8)
         k = check(lib().bb_examples_fetch(self.h, first_game, n_games, ptr(rec), cap, ptr(offs), ptr(win)))
+        return rec[:k], offs, win
+
+    def selfplay_headers(self, first_game=0, n_games=None):
+        """bb_selfplay_headers: int32 [n_games][4] = (n_examples, winner, plies, done)."""
+        n_games = self._n_games if n_games is None else n_games
+        hdr = np.zeros((n_games, 4), dtype=np.int32)
+        check(lib().bb_selfplay_headers(self.h, int(first_game), int(n_games), ptr(hdr)))
+        return hdr
+
+    def fetch_games(self, game_ids, n_records=None):
+        """bb_examples_fetch_games: the records of the listed (finished) games, compacted in list order."""
+        ids = np.ascontiguousarray(game_ids, dtype=np.int32)
+        cap = int(n_records) if n_records is not None else len(ids) * (self.max_plies + 1)
+        rec = np.zeros(max(cap, 1), dtype=example_dtype(self.game))
+        offs = np.zeros(len(ids) + 1, dtype=np.int32)
+        win = np.zeros(len(ids), dtype=np.int8)
+        k = check(lib().bb_examples_fetch_games(self.h, len(ids), ptr(ids), ptr(rec), cap, ptr(offs), ptr(win)))
         return rec[:k], offs, win
 
     def examples_device(self):

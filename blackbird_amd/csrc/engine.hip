@@ -212,6 +212,11 @@ struct bb_engine {
     TreeDev view[2];
     hipStream_t vstream[2] = {nullptr, nullptr};
     int vround[2] = {0, 0};
+    // kernel-tuning knobs, read from the environment ONCE in bb_create (never on the step path); not part of the API
+    struct {
+        int launch_steps = 64, queue_limit_s = 30, queue_netw = 0, queue_waves = 12;
+        bool level_budget_set = false;
+    } tune;
     bool mega = false; // persistent per-CU self-play kernel with an LDS work queue (mega2.hip.h)
     bool async_selfplay = false; // dense games, DynamicMCTS, deterministic evaluators: k_tree_async rounds
     bool dc_fused = false;       // DragonChess, DynamicMCTS, 16-filter network: one wave keeps its game for a whole launch (mega_dc.hip.h)
@@ -424,21 +429,28 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     d.pool_g0 = 0;
     d.noise_alpha = cfg->alpha;
     d.lid_stride = cfg->n_slots;
-    if (const char *env = getenv("BB_LEVEL_BUDGET")) {
-        int v = atoi(env);
-        if (v >= 1) d.level_budget = v;
+    auto env_int = [](const char *name, int dflt) {
+        const char *v = getenv(name);
+        return v ? atoi(v) : dflt;
+    };
+    if (int v = env_int("BB_LEVEL_BUDGET", 0); v >= 1) {
+        d.level_budget = v;
+        e->tune.level_budget_set = true;
+    }
+    e->tune.launch_steps = env_int("BB_LAUNCH_STEPS", 64);
+    e->tune.queue_limit_s = env_int("BB_QUEUE_LIMIT_S", 30);
+    e->tune.queue_netw = env_int("BB_QUEUE_NETW", 0);
+    e->tune.queue_waves = env_int("BB_QUEUE_WAVES", 12);
+    if (cfg->launch < 0 || cfg->launch > BB_LAUNCH_ROUNDS || cfg->net_form < 0 || cfg->net_form > BB_NET_FORM_SPLIT) {
+        delete e;
+        return fail(BB_ERR_ARG, "bad bb_config.launch / net_form");
     }
     e->async_selfplay = cfg->game != BB_GAME_DRAGONCHESS && cfg->mcts_kind == BB_MCTS_DYNAMIC &&
-                        cfg->evaluator != BB_EVAL_ROLLOUT;
-    if (const char *env = getenv("BB_ASYNC")) e->async_selfplay = e->async_selfplay && atoi(env) != 0;
-    e->mega = e->async_selfplay && cfg->evaluator == BB_EVAL_NET;
-    if (const char *env = getenv("BB_MEGA")) e->mega = e->mega && atoi(env) != 0;
-    e->dc_fused = cfg->game == BB_GAME_DRAGONCHESS && cfg->mcts_kind == BB_MCTS_DYNAMIC && cfg->evaluator == BB_EVAL_NET;
-    if (const char *env = getenv("BB_MEGA")) e->dc_fused = e->dc_fused && atoi(env) != 0;
-    if (const char *env = getenv("BB_TREE_GPW")) {
-        int v = atoi(env);
-        if (v >= 1 && v <= 64 / e->info.S) d.gpw = v;
-    }
+                        cfg->evaluator != BB_EVAL_ROLLOUT && cfg->launch != BB_LAUNCH_LOCKSTEP;
+    e->mega = e->async_selfplay && cfg->evaluator == BB_EVAL_NET && cfg->launch == BB_LAUNCH_AUTO;
+    e->dc_fused = cfg->game == BB_GAME_DRAGONCHESS && cfg->mcts_kind == BB_MCTS_DYNAMIC && cfg->evaluator == BB_EVAL_NET &&
+                  cfg->launch == BB_LAUNCH_AUTO;
+    if (int v = env_int("BB_TREE_GPW", 0); v >= 1 && v <= 64 / e->info.S) d.gpw = v;
     d.temp = 1.0;
     GAME_SWITCH(cfg->game, rc = engine_alloc<G>(e); break);
     if (rc) {
@@ -447,7 +459,7 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     }
     e->n_views = 1;
     if (e->async_selfplay && !e->mega && cfg->evaluator == BB_EVAL_NET && cfg->n_slots >= 512) e->n_views = 2;
-    if (const char *env = getenv("BB_GROUPS")) e->n_views = (atoi(env) == 2 && e->async_selfplay && cfg->n_slots >= 2) ? 2 : 1;
+    if (const char *env = getenv("BB_GROUPS")) e->n_views = (atoi(env) == 2 && e->async_selfplay && cfg->n_slots >= 2) ? 2 : 1; // (tuning)
     e->vstream[0] = e->stream;
     if (e->n_views == 2) HIPCHK(hipStreamCreateWithFlags(&e->vstream[1], hipStreamNonBlocking));
     GAME_SWITCH(cfg->game, make_views<G>(e); break);
@@ -635,8 +647,8 @@ static int load_general_weights(bb_engine *e, const bb_net_weights *w) {
     g.w0 = d_w0;
     g.wt = (const f32x4 *)d_wt;
     g.epi = d_epi;
-    // the tower layers' operands as three bf16 planes (gnet_x3.hip.h); BB_NET_X3=0 keeps the float32-MFMA layers
-    const bool want3 = R > 0 && !(getenv("BB_NET_X3") && atoi(getenv("BB_NET_X3")) == 0);
+    // the tower layers' operands as three bf16 planes (gnet_x3.hip.h); BB_NET_FORM_F32 keeps the float32-MFMA layers
+    const bool want3 = R > 0 && e->cfg.net_form != BB_NET_FORM_F32;
     if (want3) {
         static const int slice_taps[4][2] = {{0, 1}, {3, 4}, {6, 7}, {2, 5}};
         const size_t per = GX3_PAIR_B / 2; // uint16 elements per (fb, cb) block
@@ -842,7 +854,7 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     HIPCHK(hipSetDevice(e->cfg.device));
     const int F = w->F, C = w->C, R = w->R, D = w->D, A = w->A;
     const int steps0 = (9 * C + 3) / 4;
-    e->general_net = F != 16 || (getenv("BB_GNET") && atoi(getenv("BB_GNET")) != 0);
+    e->general_net = F != 16 || e->cfg.general_net != 0;
     if (e->general_net) {
         int rc = load_general_weights(e, w);
         if (rc) return rc;
@@ -906,9 +918,9 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     if (!wt.empty()) HIPCHK(hipMemcpy(d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_epi, epi.data(), epi.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_head, head.data(), head.size() * 4, hipMemcpyHostToDevice));
-    // the bf16-pipe form of the same network (dense games, 16 filters); BB_NET_X3=0 keeps the float32 MFMA path
+    // the bf16-pipe form of the same network (every game, 16 filters); BB_NET_FORM_F32 keeps the float32 MFMA path
     {
-        const bool want = F == 16 && C <= 32 && !e->general_net && !(getenv("BB_NET_X3") && atoi(getenv("BB_NET_X3")) == 0);
+        const bool want = F == 16 && C <= 32 && !e->general_net && e->cfg.net_form != BB_NET_FORM_F32;
         if (want) {
             std::vector<uint16_t> xw0, xw12, xw3, xw8, xwh;
             pack_x3(w, xw0, xw12, xw3, xw8, xwh);
@@ -945,7 +957,7 @@ extern "C" int bb_load_weights(bb_engine *e, const bb_net_weights *w) {
     nd.eps = e->cfg.epsilon;
     nd.inv_alpha = 1.0f / nd.alpha;
     nd.inv_beta = 1.0f / (1.0f - nd.alpha);
-    nd.dbg = getenv("BB_NET_DBG") ? atoi(getenv("BB_NET_DBG")) : 0; // ablation switches (timing experiments only; results are wrong when set)
+    nd.dbg = 0; // (ablation switches exist in diagnostic builds only: bb_timing_net, -DBB_DIAG)
     e->has_weights = true;
     e->net_F = F;
     e->net_C = C;
@@ -1348,7 +1360,7 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
             // given each of its games the requested visits, ~35 ms after the fastest one -- 4 % of a 16-step launch.
             TreeDev &d = e->dev;
             int nb = (d.n_slots + 15) / 16;
-            int per_launch = (getenv("BB_LAUNCH_STEPS") ? atoi(getenv("BB_LAUNCH_STEPS")) : 64) * (e->sims_now > 0 ? e->sims_now : 1);
+            int per_launch = e->tune.launch_steps * (e->sims_now > 0 ? e->sims_now : 1);
             if (per_launch > (1 << 30) / d.n_slots) per_launch = (1 << 30) / d.n_slots; // the launch's visit pool is an int
             const int all_rounds = rounds;
           for (int done_rounds = 0; done_rounds < all_rounds; done_rounds += per_launch) {
@@ -1357,16 +1369,16 @@ static int selfplay_rounds_async(bb_engine *e, int rounds) {
             if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
             TreeDev dm = d;
             // tree levels per call: 10 / 12 / 16 / 20 / 24 -> 155.6 / 155.8 / 153.6 / 151.6 / 151.2 M sims/s (Connect4 @800, bf16-pipe network)
-            if (!getenv("BB_LEVEL_BUDGET")) dm.level_budget = 12;
+            if (!e->tune.level_budget_set) dm.level_budget = 12;
             // the launch's visits: 7/8 dealt to the workgroups (per slot), the rest in the launch-wide pool (mega2.hip.h)
             const int own = rounds - (rounds + 7) / 8;
             k_set_i32<<<1, 1, 0, e->stream>>>(d.visit_pool, d.n_slots * (rounds - own));
-            const int lim = getenv("BB_QUEUE_LIMIT_S") ? atoi(getenv("BB_QUEUE_LIMIT_S")) : 30;
-            const int netw = getenv("BB_QUEUE_NETW") ? atoi(getenv("BB_QUEUE_NETW")) : 8; // network waves of the 12 (tuning)
+            const int lim = e->tune.queue_limit_s;
+            const int netw = e->tune.queue_netw ? e->tune.queue_netw : 8; // network waves of the 12 (tuning)
             if (e->x3.w0) { // bf16-pipe network: 8 waves of 256 VGPRs -- Connect4 5 network + 3 tree waves, TicTacToe 4 + 4
                 if constexpr (G::S <= 8) {
-                    const int waves = getenv("BB_QUEUE_WAVES") ? atoi(getenv("BB_QUEUE_WAVES")) : 12;
-                    const int nw = getenv("BB_QUEUE_NETW") ? netw : (waves == 12 ? 8 : 5);
+                    const int waves = e->tune.queue_waves;
+                    const int nw = e->tune.queue_netw ? netw : (waves == 12 ? 8 : 5);
 #define QX3(NW, WV) k_selfplay_queue<G, NW, true, WV><<<nb, WV * 64, 0, e->stream>>>(dm, e->net, e->x3, e->cfg.noise_on, lim, own)
                     if (waves == 12) { // 8 network + 4 tree waves of 168 VGPRs (default); BB_QUEUE_WAVES=8: 5 + 3 (6 + 2) waves of 256
                         if (nw == 6) QX3(6, 12);
@@ -1556,6 +1568,63 @@ extern "C" int bb_examples_fetch(bb_engine *e, int first_game, int n_games, void
     return total;
 }
 
+extern "C" int bb_selfplay_headers(bb_engine *e, int first_game, int n_games, int32_t *hdr_out) {
+    if (!e || first_game < 0 || n_games <= 0 || first_game + n_games > e->cfg.max_games || !hdr_out) return fail(BB_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(sync_all(e));
+    HIPCHK(hipMemcpy(hdr_out, e->dev.game_hdr + (size_t)first_game * 4, (size_t)n_games * 16, hipMemcpyDeviceToHost));
+    return BB_OK;
+}
+
+// record r of the compacted output <- record (r - off[g]) of game ids[g]: one thread per 16 bytes
+__global__ void __launch_bounds__(256) k_gather_examples(const uint8_t *store, size_t game_stride, int eb16, int n, const int32_t *ids,
+                                                         const int32_t *off, uint4 *out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)off[n] * eb16;
+    if (i >= total) return;
+    const int rec = (int)(i / eb16), part = (int)(i % eb16);
+    int lo = 0, hi = n - 1; // the game this record belongs to: last g with off[g] <= rec
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= rec) lo = mid;
+        else hi = mid - 1;
+    }
+    out[i] = ((const uint4 *)(store + (size_t)ids[lo] * game_stride))[(size_t)(rec - off[lo]) * eb16 + part];
+}
+
+extern "C" int bb_examples_fetch_games(bb_engine *e, int n, const int32_t *game_ids, void *records_out, int max_records,
+                                       int32_t *game_offsets_out, int8_t *winner_out) {
+    if (!e || n <= 0 || !game_ids || !records_out) return fail(BB_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(sync_all(e));
+    const size_t eb = (size_t)e->info.example_bytes, per = (size_t)(e->cfg.max_plies + 1) * eb;
+    if (eb % 16) return fail(BB_ERR_ARG, "example records are copied in 16-byte units");
+    std::vector<int32_t> hdr((size_t)e->cfg.max_games * 4);
+    HIPCHK(hipMemcpy(hdr.data(), e->dev.game_hdr, hdr.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> off((size_t)n + 1, 0);
+    for (int g = 0; g < n; g++) {
+        const int id = game_ids[g];
+        if (id < 0 || id >= e->cfg.max_games) return fail(BB_ERR_ARG, "game id %d out of range", id);
+        const int done = hdr[(size_t)id * 4 + 3];
+        if (winner_out) winner_out[g] = done ? (int8_t)hdr[(size_t)id * 4 + 1] : (int8_t)-2;
+        off[g + 1] = off[g] + (done ? hdr[(size_t)id * 4 + 0] : 0);
+    }
+    if (game_offsets_out) memcpy(game_offsets_out, off.data(), off.size() * 4);
+    const int total = off[n];
+    if (total > max_records) return fail(BB_ERR_CAPACITY, "records_out too small");
+    if (total == 0) return 0;
+    DevBuf d_ids, d_off, d_out;
+    if (d_ids.alloc((size_t)n * 4) || d_off.alloc(((size_t)n + 1) * 4) || d_out.alloc((size_t)total * eb)) return BB_ERR_HIP;
+    HIPCHK(hipMemcpy(d_ids.p, game_ids, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    k_gather_examples<<<nblk((size_t)total * (eb / 16)), 256, 0, e->stream>>>(e->dev.examples, per, (int)(eb / 16), n, (const int32_t *)d_ids.p,
+                                                                            (const int32_t *)d_off.p, (uint4 *)d_out.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(sync_all(e));
+    HIPCHK(hipMemcpy(records_out, d_out.p, (size_t)total * eb, hipMemcpyDeviceToHost));
+    return total;
+}
+
 extern "C" int bb_examples_device(bb_engine *e, void **ptr_out, uint64_t *bytes_out, uint64_t *record_bytes_out,
                                   int32_t **game_hdr_out) {
     if (!e) return fail(BB_ERR_ARG, "null engine");
@@ -1569,6 +1638,9 @@ extern "C" int bb_examples_device(bb_engine *e, void **ptr_out, uint64_t *bytes_
 extern "C" int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, double *ms_per_launch_out) {
     if (!e || iters <= 0) return fail(BB_ERR_ARG, "bad arguments");
     if (!e->has_weights) return fail(BB_ERR_WEIGHTS, "bb_load_weights has not been called");
+#ifndef BB_DIAG
+    if (ablate) return fail(BB_ERR_ARG, "the ablation switches exist in diagnostic builds only (-DBB_DIAG)");
+#endif
     HIPCHK(hipSetDevice(e->cfg.device));
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a));

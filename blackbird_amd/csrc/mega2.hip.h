@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
         const int li = (l64 / S) * TREEW + tw, lane = l64 % S; // games are dealt round-robin to the tree waves
         const bool mine = l64 < GPT * S && li < GW && g0 + li < d.n_slots;
         const int g = li; // local game number: index of the LDS copies
-        bool alive = mine; // false once the slot has run out of games
+        bool alive = mine && d.game_lid[mine ? g : 0] >= 0; // false once the slot has run out of games (or never had one)
 #ifdef BB_STAMPS
         long long t_work = 0, t_all0 = clock64(), n_calls = 0, n_lanes = 0, t_pick = 0, n_pick = 0;
 #endif
@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
         for (;;) {
             int stt = mine ? (int)*(volatile uint8_t *)&gstate[GSI(li)] : 1;
             const int pool = lds_load(&wg_pool), dry = lds_load(&wg_dry);
-            if (pool < CHUNK / 4 && !dry) { // (wave-uniform) top the workgroup's share up before it runs out
+            if (pool < CHUNK / 4 && !dry && __any(alive)) { // (wave-uniform) top the workgroup's share up before it runs out
                 if (l64 == 0 && atomicCAS(&wg_refill, 0, 1) == 0) {
                     int old = atomicSub(d.visit_pool, CHUNK);
                     int got = old < 0 ? 0 : old < CHUNK ? old : CHUNK;
@@ -536,7 +536,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
                     __threadfence_block();
                     *(volatile int *)&wg_refill = 0;
                 }
-                if (pool <= 0) continue; // another wave's refill is on its way
+                if (pool <= 0) { // another wave's refill is on its way: wait for it like every other wait, bounded by wall-clock time
+                    __builtin_amdgcn_s_sleep(1);
+                    int late = wall_clock64() - t_start > t_limit || lds_load(&qc.abort_flag);
+                    if (__builtin_amdgcn_readfirstlane(late)) {
+                        qc.abort_flag = 1;
+                        break;
+                    }
+                    continue;
+                }
             }
             bool ready = mine && alive && pool > 0 && stt != 1;
             bool busy = mine && ((alive && pool > 0) || (alive && !dry) || stt == 1); // visits left to draw, or a leaf of mine is in flight

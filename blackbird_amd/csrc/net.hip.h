@@ -47,8 +47,13 @@ struct NetDev {
     uint64_t seed;
     float alpha, eps;
     float inv_alpha, inv_beta; // 1 / alpha and 1 / (1 - alpha) (float32 quotients, formed once on the host)
-    int dbg; // ablation switches for bb_timing_net (0 in production): 1 no heads, 2 no tower, 4 no first conv
+    int dbg; // ablation switches for bb_timing_net, looked at in diagnostic builds only (ND_DBG): 1 no heads, 2 no tower, 8 no noise draws
 };
+#ifdef BB_DIAG
+#define ND_DBG(bit) (nd.dbg & (bit))
+#else
+#define ND_DBG(bit) false
+#endif
 
 #ifdef BB_STAMPS
 __device__ unsigned long long g_net_stamps[8];
@@ -291,7 +296,7 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
             const bool drawing = q < A && live;
             const uint32_t gid = game_id ? game_id[live ? pos : 0] : (uint32_t)noise;
             const uint32_t ser = serial ? (uint32_t)serial[live ? pos : 0] : (uint32_t)pos;
-            float r = (nd.dbg & 8) ? nd.alpha : -1.0f;
+            float r = ND_DBG(8) ? nd.alpha : -1.0f;
             if (noise_ready) r = nd.alpha; // (the draws were made by the caller: persistent kernel, tree waves; see below)
             for (uint32_t k = 0; k < 32 && __any(drawing && r < 0.0f); k += 2) {
                 float mine = (drawing && r < 0.0f) ? bb_beta_pair(nd.seed, gid, ser, (uint32_t)q, ia, ib, k + sub) : -1.0f;
@@ -551,7 +556,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
     //   1  weights stream from L2: the NEXT layer's 9 weight vectors are requested while this layer's MFMAs run
     //      (36 more VGPRs); with few tiles the pixel operands of tap + 1 are requested ahead of tap's MFMAs as well
     //   2  weights in LDS (persistent kernel): weight vector and pixel operands of tap + 1 are requested ahead of tap's MFMAs
-    const int R_eff = (nd.dbg & 2) ? 0 : nd.R;
+    const int R_eff = ND_DBG(2) ? 0 : nd.R;
     const int L = 2 * R_eff;
     f32x4 wnext[WMODE == 1 ? 9 : 1];
     f32x4 enext[WMODE == 1 ? 3 : 1];
@@ -691,7 +696,7 @@ __device__ __forceinline__ void net_body(const NetDev &nd, int n, int pos0, cons
         conv_layer(2 * blk + 1, actB, actA, std::true_type{});
     }
     if constexpr (Team::PART != 0) return; // the heads are part 0's
-    if (nd.dbg & 1) {
+    if (ND_DBG(1)) {
         if (value_out && lane == 0) value_out[OI(pos0)] = acc[0][0];
         return;
     }

@@ -171,11 +171,7 @@ __device__ __forceinline__ void x3_split4(const f32x4 y, u32x2 &p1, u32x2 &p2, u
 // tile t's 27 MFMAs execute (a bf16 MFMA leaves 8 of its 16 cycles to the wave's vector instructions).
 // HEADS_OUT (persistent kernel): the wave stops after the three pooled head activations (R, R0, R1) and hands them to the
 // caller's `pooled_out` -- the value / policy tails (head_one) then run on the tree wave that picks the result up.
-#ifdef BB_DIAG
-#define X3_DBG(bit) (nd.dbg & (bit)) // ablation switches of the diagnostic build (bb_timing_net; results are wrong when set)
-#else
-#define X3_DBG(bit) false
-#endif
+#define X3_DBG(bit) ND_DBG(bit) // ablation switches of the diagnostic build (bb_timing_net; results are wrong when set)
 template <class G, bool WLDS, bool LEAN = false, bool PP = false, bool HEADS_OUT = false>
 __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, int n, int pos0, const int *slot_list,
                                             unsigned char *wl, const typename G::State *states, const int8_t *planes,

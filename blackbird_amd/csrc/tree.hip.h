@@ -840,11 +840,14 @@ __device__ BB_MOVE_BODY_ATTR void selfplay_move_body(const TreeDev &d, int g, in
         ExampleHdr *h = (ExampleHdr *)example_ptr<G>(d, lid, k);
         h->z = (w <= 0) ? 0 : (h->player == w ? 1 : -1);
     }
+    __threadfence(); // the game's records (every lane's z above) are visible device-wide before its `done` word: a host copy or a
+                     // collective may read finished games while other games are still being played
     if (lane == 0) {
         int32_t *gh = d.game_hdr + (size_t)lid * 4;
         gh[0] = ply + 1;
         gh[1] = w;
         gh[2] = ply;
+        __threadfence();
         gh[3] = 1;
         uint64_t *c = d.ctr + (size_t)g * 8;
         c[4] += 1;

@@ -993,11 +993,13 @@ __device__ void dc_selfplay_move_body(const TreeDev &d, const DCEdges &E, int g,
         ExampleHdr *h = (ExampleHdr *)(d.examples + ((size_t)lid * (d.max_plies + 1) + k) * d.example_bytes);
         h->z = (w <= 0) ? 0 : (h->player == w ? 1 : -1);
     }
+    __threadfence(); // (records before the `done` word, device-wide: see selfplay_move_body in tree.hip.h)
     if (lane == 0) {
         int32_t *gh = d.game_hdr + (size_t)lid * 4;
         gh[0] = ply + 1;
         gh[1] = w;
         gh[2] = ply;
+        __threadfence();
         gh[3] = 1;
         uint64_t *c = d.ctr + (size_t)g * 8;
         c[4] += 1;

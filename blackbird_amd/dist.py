@@ -28,10 +28,21 @@ class _DeviceMemory(object):
                                          "version": 2, "strides": None}
 
 
+def compact_records(store, hdr):
+    """store: uint8 tensor [max_games, max_plies + 1, record_bytes] (the engine's example store); hdr: int32 tensor
+    [max_games, 4] = (n_examples, winner, plies, done).  Returns the records of the FINISHED games in (game, ply) order as a
+    fresh uint8 tensor [n_records, record_bytes] on the same device -- a boolean-mask compaction, no host copy."""
+    import torch
+    per = store.shape[1]
+    n_ex = torch.where(hdr[:, 3] != 0, hdr[:, 0], torch.zeros_like(hdr[:, 0]))
+    keep = torch.arange(per, device=store.device, dtype=torch.int32)[None, :] < n_ex[:, None]
+    return store[keep]
+
+
 def engine_records_device(eng, device):
     """The finished games' example records of `eng` as a uint8 tensor [n_records, record_bytes] ON `device`, in
     (game, ply) order -- the device-side twin of Engine.fetch_examples.  No host copy: the example store and the game
-    headers are viewed in place and compacted with a boolean mask."""
+    headers are viewed in place (bb_examples_device) and compacted on the device."""
     import torch
     eng.synchronize()
     rec_ptr, _nbytes, rb, hdr_ptr = eng.examples_device()
@@ -39,9 +50,7 @@ def engine_records_device(eng, device):
     dev = torch.device(device)
     store = torch.as_tensor(_DeviceMemory(rec_ptr, (ng, per, rb), "|u1"), device=dev)
     hdr = torch.as_tensor(_DeviceMemory(hdr_ptr, (ng, 4), "<i4"), device=dev)
-    n_ex = torch.where(hdr[:, 3] != 0, hdr[:, 0], torch.zeros_like(hdr[:, 0]))
-    keep = torch.arange(per, device=dev, dtype=torch.int32)[None, :] < n_ex[:, None]
-    return store[keep]  # [n_records, rb], a fresh device tensor
+    return compact_records(store, hdr)
 
 
 def allgather_bytes(payload):
@@ -61,6 +70,16 @@ def allgather_bytes(payload):
     gathered = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(gathered, pad)
     return torch.cat([g[:n] for g, n in zip(gathered, sizes)]), sizes
+
+
+def allgather_store(store, hdr):
+    """compact_records + allgather_bytes for one example store per rank: (tensor [N, record_bytes] of every rank's finished
+    games' records in rank order, per-rank record counts).  The part of the epoch-end exchange that does not need an engine
+    (tests/test_dist_cpu.py runs it on fake stores: ragged and empty ranks)."""
+    rec = compact_records(store, hdr)
+    rb = int(store.shape[2])
+    flat, sizes = allgather_bytes(rec)
+    return flat.reshape(-1, rb), [s // rb for s in sizes]
 
 
 def allgather_engine_examples(eng, device, dtype=None):

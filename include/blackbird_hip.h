@@ -128,7 +128,22 @@ typedef struct {
     int32_t device;        /* HIP device ordinal */
     int32_t salt_per_game; /* 1: hash salt += local game index (test fixtures) */
     int32_t node_capacity; /* nodes per slot; 0 = sims_per_move*max_plies + 2 */
+    int32_t net_form;      /* BB_NET_FORM_*: the arithmetic of the conv tower (Network.getEvaluation/getPolicy, Network.py:48-64).
+                              0 = AUTO: the fastest form that meets the 1e-5 bound (the split-operand form wherever it exists) */
+    int32_t launch;        /* BB_LAUNCH_*: launch structure of bb_selfplay_step; 0 = AUTO (persistent kernels where the network
+                              fits them).  The others exist for parity checks: every structure gives the same bits */
+    int32_t general_net;   /* 1: run a 16-filter network through the launch-per-layer kernels of wider networks (parity checks) */
 } bb_config;
+
+/* bb_config.net_form */
+#define BB_NET_FORM_AUTO 0
+#define BB_NET_FORM_F32 1   /* float32 MFMA (v_mfma_f32_16x16x4_f32): bit-identical to a k-ordered fmaf chain */
+#define BB_NET_FORM_SPLIT 2 /* float32 operands as three exact bf16 planes, six bf16 MFMA products per K slice, float32
+                               accumulation: float32-grade (<= 1e-5 of the form above, tests/test_gpu_net.py), 2.4x the throughput */
+/* bb_config.launch */
+#define BB_LAUNCH_AUTO 0
+#define BB_LAUNCH_LOCKSTEP 1 /* one tree + one evaluator launch per simulation, one move launch per ply */
+#define BB_LAUNCH_ROUNDS 2   /* asynchronous rounds: k_tree_async + a compacted network launch (dense games) */
 
 typedef struct bb_engine bb_engine;
 
@@ -166,7 +181,8 @@ int bb_set_sims_per_move(bb_engine *e, int sims);
 int bb_timing_enable(bb_engine *e, int every_n);
 int bb_timing_read(bb_engine *e, double *mean_ms_out, double *min_ms_out, int *count_out);
 /* Time `iters` back-to-back launches of the network kernel over the n_slots leaf mailbox (HIP events
- * on the engine stream); ablate != 0 switches parts of the kernel off (kernel tuning only). */
+ * on the engine stream).  ablate != 0 switches parts of the kernel off: only in a diagnostic build (-DBB_DIAG; kernel tuning,
+ * results are wrong) -- the product library has no such switches and answers BB_ERR_ARG. */
 int bb_timing_net(bb_engine *e, int iters, int noise, int ablate, double *ms_per_launch_out);
 /* Which launch structure bb_selfplay_step uses: 0 lock-step (one tree + one evaluator launch per
  * simulation), 1 asynchronous rounds, 3 persistent per-CU kernel with a work queue between its tree and network
@@ -177,9 +193,9 @@ int bb_selfplay_mode(bb_engine *e);
 /* Which arithmetic the loaded network's conv tower runs in (after bb_load_weights): 0 float32 MFMA, fused 16-filter
  * tower (bit-identical to the k-ordered fmaf chain); 1 float32 MFMA, one launch per conv layer (any multiple of 16
  * filters); 2 float32 results on the bf16 matrix pipe -- every operand split exactly into three bf16 values, six MFMA
- * products per K slice, float32 accumulation (16-filter networks of Connect4 / TicTacToe; 1e-5 of form 0, not
- * bit-identical; the environment variable BB_NET_X3=0 selects form 0 instead); 3 the launch-per-layer network with its tower
- * layers in the split-operand form of 2 (BB_NET_X3=0: form 1).  Negative: BB_ERR_*. */
+ * products per K slice, float32 accumulation (every 16-filter network: Connect4, TicTacToe and DragonChess; 1e-5 of form 0, not
+ * bit-identical; bb_config.net_form = BB_NET_FORM_F32 selects form 0 instead); 3 the launch-per-layer network with its tower
+ * layers in the split-operand form of 2 (BB_NET_FORM_F32: form 1).  Negative: BB_ERR_*. */
 int bb_net_form(bb_engine *e);
 
 /* Network.getEvaluation + getPolicy for n positions (Network.py:48-64; graph NetworkFactory.py:22-183).
@@ -230,8 +246,12 @@ int bb_set_rng_stream(bb_engine *e, uint64_t seed, uint32_t first_game_id);
 /* ---- batched self-play: Blackbird.GenerateTrainingSamples (Blackbird.py:219-268) ------------- */
 /* Start `n_games` games (local ids 0..n_games-1; slot g plays ids g, g+n_slots, ...). */
 int bb_selfplay_begin(bb_engine *e, int n_games, double temp);
-/* Advance every active slot by `plies` moves (each: sims_per_move simulations, sample, record the
- * example, MoveRoot, Winner(); finished games hand their slot to the next game id). Asynchronous. */
+/* Advance the self-play by `plies` moves' worth of search per active slot (a move: sims_per_move simulations, sample, record
+ * the example, MoveRoot, Winner(); finished games hand their slot to the next game id).  Asynchronous.  In the lock-step and
+ * rounds structures every slot makes exactly `plies` moves.  The persistent kernels hand out plies x sims_per_move tree visits
+ * per slot instead: 7/8 of them go to the slots of each workgroup up front, the rest is one launch-wide pool the workgroups
+ * draw from until it is dry -- so every slot advances, by about `plies` moves, a slot in a quicker workgroup by a few more
+ * (a game's results do not depend on when its visits happen). */
 int bb_selfplay_step(bb_engine *e, int plies);
 /* 1 when every game started by bb_selfplay_begin has finished */
 int bb_selfplay_done(bb_engine *e, int *done_out, int *games_finished_out);
@@ -242,6 +262,13 @@ int bb_selfplay_done(bb_engine *e, int *done_out, int *games_finished_out);
  * Returns the number of records written (<= max_records), or a negative status. */
 int bb_examples_fetch(bb_engine *e, int first_game, int n_games, void *records_out, int max_records,
                       int32_t *game_offsets_out /* n_games+1 */, int8_t *winner_out /* n_games */);
+/* The [n_games][4] header words of games first_game ..: (n_examples, winner, plies, done).  What GenerateTrainingSamples needs
+ * to hand finished games to Conn.PutGames (Blackbird.py:266-268) while the others still play. */
+int bb_selfplay_headers(bb_engine *e, int first_game, int n_games, int32_t *hdr_out);
+/* bb_examples_fetch for a LIST of games (any order): their records are compacted on the device and come back in one copy.
+ * game_offsets_out[n + 1], winner_out[n] as in bb_examples_fetch; a game that has not finished contributes no records. */
+int bb_examples_fetch_games(bb_engine *e, int n, const int32_t *game_ids, void *records_out, int max_records,
+                            int32_t *game_offsets_out, int8_t *winner_out);
 /* The example store where it lives, for a device-to-device exchange (the epoch-end RCCL all-gather of (s, pi, z),
  * SURVEY.md 8e): records_out = device pointer to [max_games][max_plies+1] records of record_bytes each (layout above),
  * game_hdr_out = device pointer to int32 [max_games][4] = {n_examples, winner, plies, done}; game g's records are the

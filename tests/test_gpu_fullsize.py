@@ -183,3 +183,28 @@ def test_dragonchess_results_do_not_depend_on_the_slot_count():
     assert a[3]["sims"] == b[3]["sims"] and a[3]["sum_depth"] == b[3]["sum_depth"]
     r = a[0]
     assert (r["total"][r["n_children"] > 0] >= DC_SIMS - 1).all()  # every search had the full 400 simulations
+
+
+def test_every_slot_advances_when_workgroups_outnumber_the_chip():
+    """More 16-game workgroups than the persistent kernel can keep resident (one per CU): the first-resident ones must not
+    drain the launch's visits.  Every workgroup owns 7/8 of its slots' visits (mega2.hip.h), so after one step of two moves'
+    worth of search every slot has moved at least once -- and the games are still the ones a one-slot-per-game run on few
+    slots plays (schedule independence at this size is test_results_do_not_depend_on_the_slot_count's subject)."""
+    n_cu = 256
+    n_slots = 16 * n_cu * 2 + 16 * 5 + 3   # 517 workgroups of 16, the last one ragged
+    sims = 16
+    eng = _lib.Engine(_lib.GAME_CONNECT4, n_slots=n_slots, sims_per_move=sims, evaluator=_lib.EVAL_NET, seed=99, noise_on=True,
+                      max_games=n_slots)
+    eng.load_weights(W.flatten(W.init_weights(3, 16, 4, 16, 7, seed=0)))
+    assert eng.selfplay_mode() == 3
+    eng.selfplay_begin(n_slots, 1.0)
+    eng.selfplay_step(2)
+    eng.synchronize()
+    cnt = eng.counters()
+    assert cnt["overflow"] == 0
+    roots = eng.root_states().reshape(n_slots, -1).view(np.uint64)
+    stones = np.array([bin(int(a & 0x00FFFFFFFFFFFFFF)).count("1") + bin(int(b & 0x00FFFFFFFFFFFFFF)).count("1") for a, b in roots[:, :2]])
+    assert stones.min() >= 1, f"{int((stones == 0).sum())} of {n_slots} slots did not move"
+    # the visits handed out are the launch's: 2 moves' worth per slot (a visit completes >= 1 simulation)
+    assert cnt["sims"] >= n_slots * 2 * sims * 7 // 8
+    eng.close()

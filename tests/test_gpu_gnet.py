@@ -1,7 +1,6 @@
 """-m gpu: the general-filter-count network path (csrc/gnet.hip.h: one implicit-GEMM launch per conv layer) vs the
 oracle's float32 restatement, tolerance 1e-5 (BASELINE.json north_star), and vs the fused F=16 kernels, which it
-must reproduce bit for bit when forced onto a 16-filter network (BB_GNET=1)."""
-import os
+must reproduce bit for bit when forced onto a 16-filter network (bb_config.general_net)."""
 
 import numpy as np
 import pytest
@@ -13,12 +12,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-def _check(orc, game, F, R, n, seed, perturb=True):
+def _check(orc, game, F, R, n, seed, perturb=True, form=_lib.NET_FORM_AUTO):
     gi = _lib.game_info(game)
     flat = W.flatten(W.init_weights(gi.C, F, R, 16, gi.A, seed=seed, perturb=perturb))
-    eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)
+    eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET, net_form=form)
     eng.load_weights(flat)
-    assert eng.net_form() == (1 if os.environ.get("BB_NET_X3") == "0" or R == 0 else 3)
+    assert eng.net_form() == (1 if form == _lib.NET_FORM_F32 or R == 0 else 3)
     rng = np.random.RandomState(n + F)
     b, pl = boards_for(game, rng, n)
     st = _lib.pack_grid(game, b, pl)
@@ -30,7 +29,7 @@ def _check(orc, game, F, R, n, seed, perturb=True):
     assert np.max(np.abs(v1 - ov)) <= TOL
     assert np.max(np.abs(l1 - ol) / np.maximum(1.0, np.abs(ol))) <= TOL
     assert np.max(np.abs(p1 - op)) <= TOL
-    if eng.net_form() == 1 and os.environ.get("BB_NET_X3") == "0":
+    if eng.net_form() == 1 and form == _lib.NET_FORM_F32:
         assert np.mean(l1 == ol) > 0.99  # float32-MFMA layers: the K order of the oracle's fmaf chains
     perm = rng.permutation(n)  # batch invariance, also across workgroup boundaries
     v3, l3, p3 = eng.net_eval(states=st[perm])
@@ -42,6 +41,8 @@ def _check(orc, game, F, R, n, seed, perturb=True):
 @pytest.mark.parametrize("F,R,n", [(32, 2, 1), (32, 2, 37), (64, 3, 9), (48, 1, 130), (128, 2, 21)])
 def test_general_filters_vs_oracle(orc, game, F, R, n):
     _check(orc, game, F, R, n, seed=21)
+    if (F, n) in ((32, 37), (64, 9)):  # the float32-MFMA layers (BB_NET_FORM_F32): the oracle's own K order
+        _check(orc, game, F, R, n, seed=21, form=_lib.NET_FORM_F32)
 
 
 def test_c5_shape_vs_oracle(orc):
@@ -49,7 +50,7 @@ def test_c5_shape_vs_oracle(orc):
     _check(orc, _lib.GAME_CONNECT4, 256, 20, 3, seed=5, perturb=False)
 
 
-def test_general_path_equals_fused_path_at_16_filters(monkeypatch):
+def test_general_path_equals_fused_path_at_16_filters():
     """The general-filter kernels and the fused float32-MFMA tower are the same k-ordered fmaf chains: identical bits.  The
     default 16-filter path of the dense games runs on the bf16 matrix pipe with three-way split operands (net_x3.hip.h):
     float32 products, another summation order -- within the 1e-5 of the north star, not bit-identical."""
@@ -60,10 +61,8 @@ def test_general_path_equals_fused_path_at_16_filters(monkeypatch):
     b, pl = boards_for(game, rng, 77)
     st = _lib.pack_grid(game, b, pl)
     outs = {}
-    for name, gnet, x3 in (("fused f32", "0", "0"), ("general", "1", "0"), ("fused x3", "0", "1")):
-        monkeypatch.setenv("BB_GNET", gnet)
-        monkeypatch.setenv("BB_NET_X3", x3)
-        eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET, noise_on=True)
+    for name, gnet, form in (("fused f32", False, _lib.NET_FORM_F32), ("general", True, _lib.NET_FORM_F32), ("fused x3", False, _lib.NET_FORM_SPLIT)):
+        eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET, noise_on=True, general_net=gnet, net_form=form)
         eng.load_weights(flat)
         outs[name] = eng.net_eval(states=st)
         eng.close()
@@ -126,9 +125,8 @@ def test_large_batch_kernels_equal_small_batch_kernels(orc, F, R, n):
     eng.close()
 
 
-def test_wide_network_rounds_on_two_streams(orc, monkeypatch):
-    """BB_MEGA=0 with >= 512 slots pipelines two slot-range views on two streams; with a wide network both run the
-    general path at once and must not share activation scratch: self-play still equals the oracle's search."""
-    monkeypatch.setenv("BB_MEGA", "0")
+def test_wide_network_rounds_on_two_streams(orc):
+    """A wide network runs self-play as asynchronous rounds; with >= 512 slots two slot-range views are pipelined on two
+    streams, both run the general path at once and must not share activation scratch: self-play still equals the oracle's search."""
     from .test_gpu_net import _selfplay_vs_oracle_tree
     _selfplay_vs_oracle_tree(orc, filters=32, blocks=1, n_slots=512, n_games=24, sims=16)

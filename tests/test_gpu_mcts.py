@@ -212,7 +212,7 @@ def test_dc_selfplay_vs_oracle(orc):
     eng.close()
 
 
-def test_dc_selfplay_one_wave_per_game(orc, monkeypatch):
+def test_dc_selfplay_one_wave_per_game(orc):
     """DragonChess with the network evaluator: the default launch structure (one wave keeps its game for a whole launch,
     tree step and network in the same wave: selfplay_mode 5) must give the examples of the launch-per-simulation
     structure byte for byte, with and without prior noise, and -- noise off -- the oracle's search fed the GPU network's
@@ -222,10 +222,9 @@ def test_dc_selfplay_one_wave_per_game(orc, monkeypatch):
     n_games, sims, cap = 7, 12, 20
     flat = W.flatten(W.init_weights(17, 16, 2, 16, 4032, seed=5))
 
-    def run(mega, noise):
-        monkeypatch.setenv("BB_MEGA", mega)
+    def run(launch, noise):
         eng = _lib.Engine(game, n_slots=5, sims_per_move=sims, evaluator=_lib.EVAL_NET, seed=7, max_games=n_games,
-                          max_plies=cap, noise_on=noise)
+                          max_plies=cap, noise_on=noise, launch=launch)
         eng.load_weights(flat)
         mode = eng.selfplay_mode()
         eng.selfplay_begin(n_games, 1.0)
@@ -240,11 +239,10 @@ def test_dc_selfplay_one_wave_per_game(orc, monkeypatch):
         return rec, offs, win, mode
 
     for noise in (True, False):
-        a, b = run("1", noise), run("0", noise)
+        a, b = run(_lib.LAUNCH_AUTO, noise), run(_lib.LAUNCH_LOCKSTEP, noise)
         assert (a[3], b[3]) == (5, 0)
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[0].tobytes() == b[0].tobytes(), noise
     rec, offs, win, _m = a  # noise off
-    monkeypatch.delenv("BB_MEGA")
     ev = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)
     ev.load_weights(flat)
 

@@ -1,8 +1,8 @@
 """-m gpu: the fused MFMA tower + heads (through the C ABI) vs the oracle's float32 restatement.
-Tolerance 1e-5 on value / logits / policy (BASELINE.json north_star).  The float32-MFMA tower (BB_NET_X3=0, and every
-DragonChess / general-filter network) is bit-identical to the oracle's k-ordered fmaf chains; the default tower of the dense
-games runs on the bf16 matrix pipe with three-way split operands (exact float32 products, the MFMA's own summation order):
-measured 3e-6 relative on logits, 6e-7 on values."""
+Tolerance 1e-5 on value / logits / policy (BASELINE.json north_star).  The float32-MFMA tower (bb_config.net_form =
+BB_NET_FORM_F32) is bit-identical to the oracle's k-ordered fmaf chains; the default tower of every 16-filter network (Connect4,
+TicTacToe and DragonChess) runs on the bf16 matrix pipe with three-way split operands (exact float32 products, the MFMA's own
+summation order): measured 3e-6 relative on logits, 6e-7 on values."""
 import numpy as np
 import pytest
 
@@ -26,12 +26,12 @@ def boards_for(game, rng, n):
 @pytest.mark.parametrize("perturb", [False, True])
 @pytest.mark.parametrize("n", [1, 5, 16, 203])
 @pytest.mark.parametrize("x3", ["1", "0"])
-def test_net_vs_oracle(orc, monkeypatch, game, og, perturb, n, x3):
-    monkeypatch.setenv("BB_NET_X3", x3)
+def test_net_vs_oracle(orc, game, og, perturb, n, x3):
     gi = _lib.game_info(game)
     w = W.init_weights(gi.C, 16, 4, 16, gi.A, seed=11, perturb=perturb)
     flat = W.flatten(w)
-    eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)
+    eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET,
+                      net_form=_lib.NET_FORM_AUTO if x3 == "1" else _lib.NET_FORM_F32)
     eng.load_weights(flat)
     assert eng.net_form() == (2 if x3 == "1" else 0)
     rng = np.random.RandomState(n)
@@ -56,13 +56,16 @@ def test_net_vs_oracle(orc, monkeypatch, game, og, perturb, n, x3):
     eng.close()
 
 
-def test_net_dc_vs_oracle(orc):
-    """DragonChess network: 17 input planes, 8x8, 4032-wide policy head."""
+@pytest.mark.parametrize("form", [_lib.NET_FORM_AUTO, _lib.NET_FORM_F32])
+def test_net_dc_vs_oracle(orc, form):
+    """DragonChess network: 17 input planes, 8x8, 4032-wide policy head -- in the default split-operand form (1e-5 of the oracle)
+    and in the float32-MFMA form (tower + value head are the oracle's fmaf chains)."""
     game = _lib.GAME_DRAGONCHESS
     w = W.init_weights(17, 16, 2, 16, 4032, seed=13, perturb=True)
     flat = W.flatten(w)
-    eng = _lib.Engine(game, n_slots=2, sims_per_move=2, evaluator=_lib.EVAL_NET, max_plies=8)
+    eng = _lib.Engine(game, n_slots=2, sims_per_move=2, evaluator=_lib.EVAL_NET, max_plies=8, net_form=form)
     eng.load_weights(flat)
+    assert eng.net_form() == (2 if form == _lib.NET_FORM_AUTO else 0)
     rng = np.random.RandomState(5)
     n = 11
     boards = np.zeros((n, 8, 8), dtype=np.int8)
@@ -78,7 +81,8 @@ def test_net_dc_vs_oracle(orc):
     assert np.max(np.abs(v1 - ov)) <= TOL
     assert np.max(np.abs(l1 - ol) / np.maximum(1.0, np.abs(ol))) <= TOL
     assert np.max(np.abs(p1 - op)) <= TOL and np.allclose(p1.sum(1), 1.0, atol=1e-4)
-    assert np.array_equal(v1, ov) or np.max(np.abs(v1 - ov)) <= 2e-7  # tower + value head are the oracle's fmaf chains
+    if form == _lib.NET_FORM_F32:
+        assert np.array_equal(v1, ov) or np.max(np.abs(v1 - ov)) <= 2e-7  # tower + value head are the oracle's fmaf chains
     eng.close()
 
 
@@ -177,16 +181,15 @@ def test_empty_and_single_position_batches():
 
 
 @pytest.mark.parametrize("game,og", [(_lib.GAME_CONNECT4, 0), (_lib.GAME_TICTACTOE, 1)])
-def test_every_positions_per_wave_variant_matches_oracle(orc, monkeypatch, game, og):
+def test_every_positions_per_wave_variant_matches_oracle(orc, game, og):
     """The fused kernel is instantiated for 1, 2 and the LDS-filling number of positions per wave (12 for TicTacToe, 4 for
     Connect4), picked by batch size; the tile counts (1, 2, 7 / 3, 6, 11 tiles of 16 pixels) go through different operand
     schedules.  All of them against the oracle, logits bit-identical.  (Round 2 found a compiler reordering across the
     cross-lane LDS hand-over between layers that only struck the one-tile variant: net.hip.h wave_lds_handover.)
-    These are the float32-MFMA kernels (BB_NET_X3=0); the bf16-pipe form has one position per wave at every batch size."""
-    monkeypatch.setenv("BB_NET_X3", "0")
+    These are the float32-MFMA kernels (BB_NET_FORM_F32); the bf16-pipe form has one position per wave at every batch size."""
     gi = _lib.game_info(game)
     flat = W.flatten(W.init_weights(gi.C, 16, 4, 16, gi.A, seed=2, perturb=True))
-    eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)
+    eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET, net_form=_lib.NET_FORM_F32)
     eng.load_weights(flat)
     rng = np.random.RandomState(1)
     b, pl = boards_for(game, rng, 3000)
@@ -207,7 +210,7 @@ def test_split_operand_tower_every_tap_and_plane_contributes(game):
     has one bit in each plane; placed on one tap of the first conv (a network without residual blocks, identity batch norm) the
     value head sees it only if that tap's slice carried all three planes.  The first version lost plane 2 of every K = 32 slice:
     a K = 32 MFMA directly followed by a K = 16 MFMA on the same accumulator reads its SrcC too early on gfx950 / ROCm 7.2
-    (the tower uses one MFMA kind now: net_x3.hip.h x3_k16).  Checked through the public outputs: the value of an empty board equals the float64 statement within
+    (the tower uses one MFMA kind now and tap 8 is three plane-concatenated K = 32 products: net_x3.hip.h).  Checked through the public outputs: the value of an empty board equals the float64 statement within
     1e-6 only when nothing is lost (a lost plane 2 costs 1e-3)."""
     gi = _lib.game_info(game)
     H, Wd, _ = _lib.GRID[game]
@@ -242,3 +245,118 @@ def test_split_operand_tower_every_tap_and_plane_contributes(game):
         expect = np.tanh(hdn @ w["value/dense_2/kernel"].astype(np.float64).reshape(-1) + float(w["value/dense_2/bias"][0]))
         assert abs(float(v[0]) - expect) <= 1e-6, (tap, float(v[0]), expect)
         del x0
+
+
+# ---- the split-operand arithmetic over its envelope (bb_config.net_form AUTO / SPLIT) -------------------------------------
+def _forward64(w, planes):
+    """The graph of NetworkFactory.py:22-183 in float64 numpy (NHWC, SAME padding, batch-norm epsilon 1e-3): an independent
+    statement of what both the float32 oracle and the GPU forms approximate.  Returns value, logits."""
+    x = planes.astype(np.float64)
+
+    def conv(t, k, b):
+        kh = k.shape[0] // 2
+        tp = np.pad(t, ((0, 0), (kh, kh), (kh, kh), (0, 0)))
+        out = np.zeros(t.shape[:3] + (k.shape[3],))
+        for dy in range(k.shape[0]):
+            for dx in range(k.shape[1]):
+                out += np.einsum("nhwc,cf->nhwf", tp[:, dy:dy + t.shape[1], dx:dx + t.shape[2], :], k[dy, dx].astype(np.float64))
+        return out + b.astype(np.float64)
+
+    def bn(t, p):
+        g, b, m, v = (w[f"{p}/{n}"].astype(np.float64) for n in ("gamma", "beta", "moving_mean", "moving_variance"))
+        return g * (t - m) / np.sqrt(v + 1e-3) + b
+
+    relu = lambda t: np.maximum(t, 0.0)
+    t = relu(bn(conv(x, w["resTower/conv_block/conv/kernel"], w["resTower/conv_block/conv/bias"]), "resTower/conv_block/batch_norm"))
+    i = 0
+    while f"resTower/block_{i}/conv_1/kernel" in w:
+        u = relu(bn(conv(t, w[f"resTower/block_{i}/conv_1/kernel"], w[f"resTower/block_{i}/conv_1/bias"]), f"resTower/block_{i}/batch_norm_1"))
+        u = bn(conv(u, w[f"resTower/block_{i}/conv_2/kernel"], w[f"resTower/block_{i}/conv_2/bias"]), f"resTower/block_{i}/batch_norm_2")
+        t = relu(u + t)
+        i += 1
+    v = relu(bn(conv(t, w["value/convolution/kernel"], w["value/convolution/bias"]), "value/batch_norm"))
+    v = (v @ w["value/dense_1/kernel"].astype(np.float64) + w["value/dense_1/bias"]).sum(axis=(1, 2))
+    v = np.tanh(relu(v) @ w["value/dense_2/kernel"].astype(np.float64) + w["value/dense_2/bias"])[:, 0]
+    p = relu(bn(conv(t, w["policy/convolution/kernel"], w["policy/convolution/bias"]), "policy/batch_norm"))
+    logits = (p @ w["policy/policy/kernel"].astype(np.float64) + w["policy/policy/bias"]).sum(axis=(1, 2))
+    return v, logits
+
+
+def _layer_names(blocks):
+    names = [("resTower/conv_block/conv", "resTower/conv_block/batch_norm")]
+    for i in range(blocks):
+        names += [(f"resTower/block_{i}/conv_{j}", f"resTower/block_{i}/batch_norm_{j}") for j in (1, 2)]
+    return names
+
+
+def _rescaled(w, layer, k, blocks):
+    """Kernel, bias and moving mean of one conv layer times 2^k, its batch-norm gamma divided by 2^k: the network function is
+    unchanged in exact arithmetic, and every scaling is a power of two -- exact in float32 and in every bf16 plane."""
+    conv, bnp = _layer_names(blocks)[layer]
+    out = {n: a.copy() for n, a in w.items()}
+    s = np.float32(2.0) ** k
+    out[conv + "/kernel"] = (w[conv + "/kernel"] * s).astype(np.float32)
+    out[conv + "/bias"] = (w[conv + "/bias"] * s).astype(np.float32)
+    out[bnp + "/moving_mean"] = (w[bnp + "/moving_mean"] * s).astype(np.float32)
+    out[bnp + "/gamma"] = (w[bnp + "/gamma"] / s).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("game", [_lib.GAME_CONNECT4, _lib.GAME_DRAGONCHESS])
+def test_split_operand_envelope(orc, game):
+    """The default arithmetic (float32 operands as three exact bf16 planes, six bf16 MFMA products, float32 accumulation) over the
+    range a trained network can reach, against the float32 oracle (north star: 1e-5) AND against a float64 statement of the
+    graph -- the split form must be as close to the exact result as a float32 fmaf chain is:
+      * one layer's kernel x 2^k with its batch-norm gamma / 2^k (k = -20 .. 20): pre-activations 1e-6 .. 1e6 times the usual,
+      * moving_variance down to 1e-8 (scale 31.6 gamma), gamma up to 64: activations beyond 1e4,
+      * kernels small enough that the third bf16 plane of a weight is a bf16 subnormal (2^-115): the hardware's treatment of
+        subnormal MFMA inputs shows here and nowhere in a realistic network."""
+    gi = _lib.game_info(game)
+    R = 4 if game == _lib.GAME_CONNECT4 else 2
+    w = W.init_weights(gi.C, 16, R, 16, gi.A, seed=31, perturb=True)
+    rng = np.random.RandomState(3)
+    if game == _lib.GAME_CONNECT4:
+        b, pl = boards_for(game, rng, 24)
+        st = _lib.pack_grid(game, b, pl)
+    else:
+        boards = np.zeros((8, 8, 8), dtype=np.int8)
+        for i in range(8):
+            m = rng.rand(8, 8) < 0.35
+            boards[i][m] = rng.choice([-6, -5, -4, -3, -2, -1, 1, 2], m.sum())
+        st = _lib.pack_dc(boards, rng.randint(1, 3, 8), rng.randint(0, 3, 8), rng.randint(0, 2, (8, 4)))
+    planes = _lib.game_encode(game, st)
+
+    def run(wts, what, tol=TOL, c64=4.0):
+        flat = W.flatten(wts)
+        eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET, max_plies=8, net_form=_lib.NET_FORM_SPLIT)
+        eng.load_weights(flat)
+        assert eng.net_form() == 2
+        v, l, p = eng.net_eval(states=st)
+        eng.close()
+        ov, ol, op = orc.net_forward(orc.NetWeights(gi.H, gi.W, gi.C, 16, R, 16, gi.A, flat), planes)
+        v64, l64 = _forward64(wts, planes)
+        den = np.maximum(1.0, np.abs(l64))
+        e_gpu, e_orc = np.max(np.abs(l - l64) / den), np.max(np.abs(ol - l64) / den)
+        print(f"{what}: |logit| <= {np.abs(l64).max():.3g}; vs oracle {np.max(np.abs(l - ol) / den):.2e}; vs float64: GPU {e_gpu:.2e}, oracle {e_orc:.2e}")
+        # two float32 forms cannot agree better than each agrees with the exact result: where float32 arithmetic itself is
+        # > 1e-5 away from float64 (logits ~1e5) the bound between them follows it
+        tol_l = max(tol, 1.25 * (e_gpu + e_orc))
+        assert np.max(np.abs(l - ol) / den) <= tol_l and np.max(np.abs(v - ov)) <= tol_l and np.max(np.abs(p - op)) <= tol_l, what
+        assert e_gpu <= max(c64 * e_orc, 2e-6), what  # as accurate as float32 arithmetic itself
+        return v, l, p
+
+    base = run(w, "base")
+    for layer, k in [(0, -20), (1, 20), (2, -12), (3, 12), (2 * R, -20), (2 * R, 20), (1, -6), (2, 6)]:
+        got = run(_rescaled(w, layer, k, R), f"layer {layer} x 2^{k}")
+        # powers of two scale every plane and every product exactly: the SAME bits as the unscaled network
+        assert np.array_equal(got[1], base[1]) and np.array_equal(got[0], base[0]), (layer, k)
+    # tiny variances and large gammas: large activations
+    big = {n: a.copy() for n, a in w.items()}
+    big["resTower/conv_block/batch_norm/moving_variance"][:] = 1e-8
+    big["resTower/conv_block/batch_norm/gamma"] *= 64.0
+    big["resTower/block_0/batch_norm_1/moving_variance"][:] = 1e-8
+    # (logits ~1e5 here: float32 arithmetic itself -- the oracle's fmaf chains -- is 2e-5 .. 5e-5 away from the float64 result;
+    # what is asserted is that the split form is as close to exact as the float32 one)
+    run(big, "variance 1e-8, gamma x 64")
+    # third plane of the weights subnormal in bf16 (|w| ~ 2^-3 x 2^-112, third plane ~ 2^-131 < 2^-126)
+    run(_rescaled(w, 1, -112, R), "layer 1 x 2^-112 (third plane subnormal)", tol=1e-4, c64=64.0)

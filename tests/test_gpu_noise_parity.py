@@ -20,11 +20,11 @@ pytestmark = pytest.mark.gpu
 ALPHA, EPS = 0.2, 0.3
 
 
-def _selfplay(game, n_slots, n_games, sims, blocks, seed, first_id, noise=True):
+def _selfplay(game, n_slots, n_games, sims, blocks, seed, first_id, noise=True, launch=_lib.LAUNCH_AUTO):
     gi = _lib.game_info(game)
     flat = W.flatten(W.init_weights(gi.C, 16, blocks, 16, gi.A, seed=21, perturb=True))
     eng = _lib.Engine(game, n_slots=n_slots, sims_per_move=sims, evaluator=_lib.EVAL_NET, seed=seed, max_games=n_games,
-                      first_game_id=first_id, noise_on=noise, alpha=ALPHA, epsilon=EPS)
+                      first_game_id=first_id, noise_on=noise, alpha=ALPHA, epsilon=EPS, launch=launch)
     eng.load_weights(flat)
     mode = eng.selfplay_mode()
     eng.selfplay_begin(n_games, 1.0)
@@ -105,16 +105,12 @@ def test_keyed_noise_is_the_oracles_beta_stream(orc):
 
 
 @pytest.mark.parametrize("game,n_slots,n_games,sims", [(_lib.GAME_CONNECT4, 37, 60, 40), (_lib.GAME_TICTACTOE, 16, 40, 24)])
-def test_launch_structures_are_byte_identical_with_noise(monkeypatch, game, n_slots, n_games, sims):
+def test_launch_structures_are_byte_identical_with_noise(game, n_slots, n_games, sims):
     """Per game the sequence of simulations is the sequential one whatever the launch structure, and the random streams
     are keyed by game / ply / node: work queue (3) == asynchronous rounds (1) == lock-step launches (0), noise on."""
     runs = {}
-    for name, env in (("queue", {}), ("rounds", {"BB_MEGA": "0"}), ("lockstep", {"BB_MEGA": "0", "BB_ASYNC": "0"})):
-        for k in ("BB_MEGA", "BB_ASYNC"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        runs[name] = _selfplay(game, n_slots, n_games, sims, 4, 5, 0)
+    for name, launch in (("queue", _lib.LAUNCH_AUTO), ("rounds", _lib.LAUNCH_ROUNDS), ("lockstep", _lib.LAUNCH_LOCKSTEP)):
+        runs[name] = _selfplay(game, n_slots, n_games, sims, 4, 5, 0, launch=launch)
     assert [runs[k][5] for k in ("queue", "rounds", "lockstep")] == [3, 1, 0]
     a = runs["queue"]
     for other in ("rounds", "lockstep"):
