@@ -1468,8 +1468,9 @@ extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
                     const int now = plies - done < cap ? plies - done : cap;
                     bool timed = e->time_every > 0 && e->ev_used + 2 <= e->ev_pool.size();
                     if (timed) HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], e->stream));
-                    k_set_i32<<<1, 1, 0, e->stream>>>(e->dev.visit_pool, e->dev.n_slots * now * e->sims_now);
-                    k_dc_selfplay_fused<<<nblk((size_t)e->dev.n_slots * 64), 256, 0, e->stream>>>(e->dev, e->edges, e->net, e->x3, e->cfg.noise_on);
+                    const int per_slot = now * e->sims_now, own = per_slot - (per_slot + 7) / 8; // 7/8 dealt to the games, the rest pooled
+                    k_set_i32<<<1, 1, 0, e->stream>>>(e->dev.visit_pool, e->dev.n_slots * (per_slot - own));
+                    k_dc_selfplay_fused<<<nblk((size_t)e->dev.n_slots * 64), 256, 0, e->stream>>>(e->dev, e->edges, e->net, e->x3, e->cfg.noise_on, own);
                     HIPCHK(hipGetLastError());
                     if (timed) {
                         HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], e->stream));

@@ -119,7 +119,7 @@ struct DCShadow {
 
 #define DC_SIM_CHUNK 20 // simulations a wave draws from the launch's pool at a time (~1 ms of work)
 
-__global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdges E_arg, NetDev nd_arg, NetX3 x3_arg, int noise_on) {
+__global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdges E_arg, NetDev nd_arg, NetX3 x3_arg, int noise_on, int own_sims) {
     using NG = NetGeom<DragonChess, 1>;
     // the tree's scratch (the 4032-float policy image) and the network's activations are never live together
     constexpr int TREE_BYTES = DC_LDS_FLOATS * 4;
@@ -178,10 +178,12 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
     if (lane < 16) ((unsigned long long *)(lds + DC_STAMP_OFF))[lane] = 0;
 #endif
     __threadfence_block();
-    // The launch has one pool of simulations (d.visit_pool = slots x plies x simulations per move) that the waves draw from
-    // in small chunks until it is dry: every wave then stops within a chunk of the others, wherever its game is in its move
-    // (sims_left carries over), instead of the launch waiting for the game with the slowest `plies` moves.
-    int chunk = 0;
+    // A wave starts with its own share of the launch's simulations (`own_sims`: 7/8 of plies x simulations per move -- so that
+    // every game advances even when more workgroups are launched than the chip holds at once); the last eighth is one pool
+    // (d.visit_pool) that the waves then draw from in small chunks until it is dry: every wave stops within a chunk of the
+    // others, wherever its game is in its move (sims_left carries over), instead of the launch waiting for the game with the
+    // slowest `plies` moves.
+    int chunk = own_sims;
     while (mine) {
         if (d.game_lid[g] < 0) break; // this slot has played its last game
         if (d.sims_left[g] <= 0) {    // MCTS.FindMove's tail and the self-play loop body (applies the last leaf first)

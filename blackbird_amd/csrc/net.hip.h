@@ -143,7 +143,11 @@ __device__ __forceinline__ void wide_head_stats(WideHead &h, PK pdk, PK pdb, int
     static_assert(A % 64 == 0, "every lane owns exactly A / 64 actions: the loops below carry no bounds test");
     constexpr int NPL = A / 64, UB = 9; // UB actions per batch: their 3 x UB weights are requested together, then consumed
     static_assert(NPL % UB == 0, "whole batches");
+    // the lane's A / 64 logits stay in registers from the GEMV to the sum (as in the dense form of head_one): one pass over the
+    // head weights -- round 2 formed every logit twice, 3 x 63 more LDS reads and 2 x 63 more fmas per lane and evaluation
+    float sv[NPL];
     float m = -INFINITY;
+#pragma unroll
     for (int k0 = 0; k0 < NPL; k0 += UB) {
         float w0[UB], w1[UB], wb[UB];
 #pragma unroll
@@ -154,22 +158,15 @@ __device__ __forceinline__ void wide_head_stats(WideHead &h, PK pdk, PK pdb, int
             wb[u] = pdb[a];
         }
 #pragma unroll
-        for (int u = 0; u < UB; u++) m = fmaxf(m, wide_logit<HW>(h.R0, h.R1, w0[u], w1[u], wb[u]));
+        for (int u = 0; u < UB; u++) {
+            sv[k0 + u] = wide_logit<HW>(h.R0, h.R1, w0[u], w1[u], wb[u]);
+            m = fmaxf(m, sv[k0 + u]);
+        }
     }
     m = wave_max_f32(m);
     float tot = 0.f;
-    for (int k0 = 0; k0 < NPL; k0 += UB) {
-        float w0[UB], w1[UB], wb[UB];
 #pragma unroll
-        for (int u = 0; u < UB; u++) {
-            const int a = lane + 64 * (k0 + u);
-            w0[u] = pdk[a];
-            w1[u] = pdk[A + a];
-            wb[u] = pdb[a];
-        }
-#pragma unroll
-        for (int u = 0; u < UB; u++) tot += wide_expterm(wide_logit<HW>(h.R0, h.R1, w0[u], w1[u], wb[u]), m); // (k ascending: the dense form's order)
-    }
+    for (int k = 0; k < NPL; k++) tot += wide_expterm(sv[k], m); // (k ascending: the dense form's order)
     tot = wave_sum_f32(tot);
     h.m = m;
     h.inv = 1.0f / tot;
