@@ -89,7 +89,7 @@ def test_results_do_not_depend_on_the_slot_count():
 DC_SIMS = 400
 
 
-def _play_dc(n_slots, n_games, prefill_plies, plies, max_plies=512, first_id=0):
+def _play_dc(n_slots, n_games, prefill_plies, plies, max_plies=512, first_id=0, to_the_end=False):
     game = _lib.GAME_DRAGONCHESS
     eng = _lib.Engine(game, n_slots=n_slots, sims_per_move=DC_SIMS, evaluator=_lib.EVAL_NET, seed=777, noise_on=True,
                       alpha=0.2, epsilon=0.3, max_games=n_games, max_plies=max_plies, first_game_id=first_id)
@@ -104,6 +104,11 @@ def _play_dc(n_slots, n_games, prefill_plies, plies, max_plies=512, first_id=0):
         eng.reset_counters()                          # the counters then describe the full-strength plies only
     for _ in range(plies):
         eng.selfplay_step(1)
+    guard = 0
+    while to_the_end and not eng.selfplay_done()[0]:  # (a launch hands out simulations, not whole moves: play on until every game is over)
+        eng.selfplay_step(2)
+        guard += 1
+        assert guard < 200
     eng.synchronize()
     cnt = eng.counters()
     done, finished = eng.selfplay_done()
@@ -175,8 +180,8 @@ def test_dragonchess_full_size_properties():
 def test_dragonchess_results_do_not_depend_on_the_slot_count():
     """1024 games on 1024 slots vs the same games on 256 slots (4 games per slot, 4x smaller pools): byte-identical
     records.  Ply cap 24 and full 400-simulation searches throughout, so every game ends (at the cap) and is compared."""
-    a = _play_dc(1024, 1024, 0, 24, max_plies=24)
-    b = _play_dc(256, 1024, 0, 96, max_plies=24)
+    a = _play_dc(1024, 1024, 0, 24, max_plies=24, to_the_end=True)
+    b = _play_dc(256, 1024, 0, 96, max_plies=24, to_the_end=True)
     assert a[5] == b[5] == 5 and a[3]["overflow"] == 0 and b[3]["overflow"] == 0
     assert a[4] == b[4] == 1024
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
