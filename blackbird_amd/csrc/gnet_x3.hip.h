@@ -30,6 +30,12 @@ struct GNetX3 {
 
 // (Measured and dropped: the activation operand of a slice fetched once per workgroup into a double-buffered LDS image and
 // read back by its four waves -- 47.1 ms against 40.1 ms per 20 x 256 batch; the L1 rate was not the limit.)
+// (Round 3, measured and dropped: tap 8 as three plane-concatenated K = 32 products -- 27 MFMAs per block and tile instead of
+// 30, as in net_x3.hip.h.  In its own loop after the slices: 40.9 ms against 39.8 (two 16-byte operand loads per tile instead of
+// three 8-byte ones; the section waits for memory, not for the matrix pipe).  As a fifth step inside the slice loop with
+// compile-time step tags: the optimiser hoists per-step 64-bit operand pointers out of the layer loop and spills 50-150
+// registers of a kernel that uses all 512 -- 48.7 ms; with buffer loads (descriptor + scalar offset + 32-bit lane offset) 73.7 ms.
+// What paces these layers is the first slice of every channel block missing to HBM, not the 10 % of padded MFMA time.)
 template <class G, int PPB, int FBW, bool LAST>
 __global__ void __launch_bounds__(256) k_gnet_conv_x3(GNetDev gd, GNetX3 gx, int layer, int n_max, const int *n_ptr,
                                                       const unsigned char *in, unsigned char *out3, float *outf, int skip,

@@ -214,3 +214,54 @@ def test_every_slot_advances_when_workgroups_outnumber_the_chip():
     # the visits handed out are the launch's: 2 moves' worth per slot (a visit completes >= 1 simulation)
     assert cnt["sims"] >= n_slots * 2 * sims * 7 // 8
     eng.close()
+
+
+def test_c5_network_full_size_in_search():
+    """BASELINE configs[4] on one GPU: 4096 concurrent Connect4 games searched with the 20-block x 256-filter network (the
+    launch-per-layer kernels, tower layers in the split-operand form, inside the asynchronous-round search).  A handful of
+    simulations per move and a ply cap of 3 keep it to seconds; what is checked does not depend on either:
+    * every record's visit counts add up to its root play count (>= playLimit - 1 on a game's first move), pi > 0 only on
+      legal moves, the terminal record has pi = 0, replaying a visited move gives the next recorded position;
+    * schedule independence: the same 4096 games on 1024 slots (four games per slot, four times smaller evaluation batches:
+      another launch shape of every conv layer) are byte-identical to the one-slot-per-game run."""
+    game, sims, cap, n = _lib.GAME_CONNECT4, 8, 3, 4096
+    flat = W.flatten(W.init_weights(3, 256, 20, 16, 7, seed=0))
+
+    def play(n_slots):
+        eng = _lib.Engine(game, n_slots=n_slots, sims_per_move=sims, evaluator=_lib.EVAL_NET, seed=31, noise_on=True, alpha=0.2,
+                          epsilon=0.3, max_games=n, max_plies=cap)
+        eng.load_weights(flat)
+        assert eng.net_form() == 3 and eng.selfplay_mode() == 1
+        eng.selfplay_begin(n, 1.0)
+        guard = 0
+        while not eng.selfplay_done()[0]:
+            eng.selfplay_step(1)
+            guard += 1
+            assert guard < 64
+        rec, offs, win = eng.fetch_examples()
+        cnt = eng.counters()
+        eng.close()
+        return rec, offs, win, cnt
+
+    rec, offs, win, cnt = play(n)
+    assert cnt["overflow"] == 0 and cnt["games_finished"] == n and len(rec) == n * (cap + 1)
+    assert cnt["evals"] <= cnt["sims"] and cnt["sims"] >= n * cap * (sims - 1)
+    r = rec.reshape(n, cap + 1)
+    assert (r["ply"] == np.arange(cap + 1)[None, :]).all() and (r["z"] == 0).all() and (win == -1).all()   # ply cap: z = 0
+    vis = r["visits"][:, :, :7].astype(np.int64)
+    assert np.array_equal(vis.sum(2), r["total"]) and (r["total"][:, cap] == 0).all()
+    assert (r["total"][:, 0] == sims - 1).all() and (r["total"][:, 1:cap] >= sims - 1).all()   # fresh root / re-used subtree
+    states = np.ascontiguousarray(rec["state"])
+    legal = _lib.game_legal(game, states).reshape(n, cap + 1, 7)
+    assert ((vis > 0) <= (legal > 0)).all()
+    for k in range(cap):   # the next recorded position follows from a visited move
+        st_k = np.ascontiguousarray(r["state"][:, k])
+        ok = np.zeros(n, dtype=bool)
+        for a in range(7):
+            nxt, status = _lib.game_apply(game, st_k.copy(), np.full(n, a, dtype=np.int32))
+            same = (nxt.reshape(n, -1) == np.ascontiguousarray(r["state"][:, k + 1]).reshape(n, -1)).all(1)
+            ok |= same & (status == 0) & (vis[:, k, a] > 0)
+        assert ok.all(), k
+    rec_b, offs_b, win_b, cnt_b = play(1024)
+    assert np.array_equal(offs, offs_b) and np.array_equal(win, win_b) and rec.tobytes() == rec_b.tobytes()
+    assert cnt_b["sims"] == cnt["sims"] and cnt_b["sum_depth"] == cnt["sum_depth"]
