@@ -24,7 +24,7 @@ EXPORTS = (
     "bb_game_encode", "bb_game_initial", "bb_create", "bb_destroy", "bb_load_weights", "bb_get_counters",
     "bb_reset_counters", "bb_synchronize", "bb_set_sims_per_move", "bb_timing_enable", "bb_timing_read", "bb_timing_net", "bb_selfplay_mode", "bb_net_form", "bb_net_eval", "bb_hash_eval", "bb_set_roots", "bb_run_sims", "bb_run_sims_masked",
     "bb_sample_moves", "bb_move_roots", "bb_get_root_states", "bb_selfplay_begin", "bb_selfplay_step",
-    "bb_selfplay_done", "bb_examples_fetch", "bb_examples_device", "bb_selfplay_headers", "bb_examples_fetch_games", "bb_net_eval_keyed", "bb_set_rng_stream", "bb_fit_slots",
+    "bb_selfplay_done", "bb_examples_fetch", "bb_examples_device", "bb_selfplay_headers", "bb_examples_fetch_games", "bb_reset_roots", "bb_node_view", "bb_net_eval_keyed", "bb_set_rng_stream", "bb_fit_slots",
 )
 
 
@@ -48,7 +48,7 @@ class Config(C.Structure):
                 ("max_games", C.c_int32), ("c_puct", C.c_double), ("seed", C.c_uint64), ("hash_salt", C.c_uint64),
                 ("first_game_id", C.c_uint32), ("noise_on", C.c_int32), ("alpha", C.c_float), ("epsilon", C.c_float),
                 ("device", C.c_int32), ("salt_per_game", C.c_int32), ("node_capacity", C.c_int32),
-                ("net_form", C.c_int32), ("launch", C.c_int32), ("general_net", C.c_int32)]
+                ("net_form", C.c_int32), ("launch", C.c_int32), ("general_net", C.c_int32), ("track_ancestors", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -109,6 +109,8 @@ def lib():
     L.bb_selfplay_done.argtypes = [vp, C.POINTER(ip), C.POINTER(ip)]
     L.bb_examples_fetch.argtypes = [vp, ip, ip, vp, ip, vp, vp]
     L.bb_selfplay_headers.argtypes = [vp, ip, ip, vp]
+    L.bb_reset_roots.argtypes = [vp]
+    L.bb_node_view.argtypes = [vp, ip, ip, vp, vp, vp, vp, vp]
     L.bb_examples_fetch_games.argtypes = [vp, ip, vp, vp, ip, vp, vp]
     L.bb_examples_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(vp)]
     for name in EXPORTS:
@@ -284,7 +286,7 @@ class Engine:
     def __init__(self, game, n_slots, sims_per_move, *, mcts_kind=MCTS_DYNAMIC, max_depth=10, evaluator=EVAL_NET,
                  c_puct=0.85, max_plies=None, max_games=None, seed=1234, hash_salt=0, first_game_id=0,
                  noise_on=False, alpha=0.2, epsilon=0.3, device=0, salt_per_game=False, node_capacity=0,
-                 net_form=0, launch=0, general_net=False):
+                 net_form=0, launch=0, general_net=False, track_ancestors=False):
         """net_form: NET_FORM_AUTO / NET_FORM_F32 / NET_FORM_SPLIT (bb_config.net_form); launch: LAUNCH_AUTO / LAUNCH_LOCKSTEP /
         LAUNCH_ROUNDS (bb_config.launch); general_net: a 16-filter network through the launch-per-layer kernels."""
         self.game = game
@@ -295,7 +297,8 @@ class Engine:
                      sims_per_move=sims_per_move, max_plies=max_plies, max_games=max_games or n_slots, c_puct=c_puct,
                      seed=seed, hash_salt=hash_salt, first_game_id=first_game_id, noise_on=int(noise_on), alpha=alpha,
                      epsilon=epsilon, device=device, salt_per_game=int(salt_per_game), node_capacity=node_capacity,
-                     net_form=int(net_form), launch=int(launch), general_net=int(bool(general_net)))
+                     net_form=int(net_form), launch=int(launch), general_net=int(bool(general_net)),
+                     track_ancestors=int(bool(track_ancestors)))
         self.cfg = cfg
         self.h = C.c_void_p()
         self.n_slots = n_slots
@@ -435,6 +438,20 @@ class Engine:
         actions = np.ascontiguousarray(actions, dtype=np.int32)
         assert actions.shape[0] == self.n_slots
         check(lib().bb_move_roots(self.h, ptr(actions)))
+
+    def reset_roots(self):
+        """bb_reset_roots: MCTS.ResetRoot for every slot."""
+        check(lib().bb_reset_roots(self.h))
+
+    def node_view(self, slot=0, node=-1):
+        """bb_node_view: dict(child, plays, value [S], state (packed), flags, legal_mask, node)."""
+        S = self.info.S
+        child, plays, value = np.zeros(S, np.int32), np.zeros(S, np.int32), np.zeros(S, np.float32)
+        state = np.zeros((1, self.info.state_bytes), dtype=np.uint8)
+        info = np.zeros(3, np.int32)
+        check(lib().bb_node_view(self.h, int(slot), int(node), ptr(child), ptr(plays), ptr(value), ptr(state), ptr(info)))
+        return dict(child=child, plays=plays, value=value, state=state.view(STATE_DTYPE[self.game]), flags=int(info[0]),
+                    legal_mask=int(np.uint32(info[1])), node=int(info[2]))
 
     def root_states(self):
         buf = np.zeros((self.n_slots, self.info.state_bytes), dtype=np.uint8)

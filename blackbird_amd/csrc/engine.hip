@@ -263,6 +263,7 @@ static int engine_alloc(bb_engine *e) {
         dalloc(e, d.sims_left, n) || dalloc(e, d.pend_leaf, n) || dalloc(e, d.pend_expand, n) ||
         dalloc(e, d.path_len, n) || dalloc(e, d.game_lid, n) || dalloc(e, d.sim_serial, n) ||
         dalloc(e, d.root_W, n) || dalloc(e, d.root_pp, n) || dalloc(e, d.path, n * G::MAXPATH) ||
+        dalloc(e, d.anc, n * (size_t)(c.max_plies + 2)) || dalloc(e, d.anc_len, n) || dalloc(e, d.top_N, n) ||
         dalloc(e, d.path_N, n * G::MAXPATH) || dalloc(e, d.path_all, n * G::MAXPATH) || dalloc(e, d.path_W, n * G::MAXPATH) || dalloc(e, d.leaf_flags, n) ||
         dalloc(e, d.leaf_game_id, n) || dalloc(e, d.leaf_serial, n) || dalloc(e, d.eval_value, n) ||
         dalloc(e, d.eval_policy, n * PSTRIDE) || dalloc(e, d.ctr, n * 8) || dalloc(e, d.evals, n) || dalloc(e, d.out_action, n) ||
@@ -315,6 +316,7 @@ static void make_views(bb_engine *e) {
         w.root += off; w.root_N += off; w.n_nodes += off; w.ply += off; w.sims_left += off; w.pend_leaf += off;
         w.pend_expand += off; w.path_len += off; w.game_lid += off; w.sim_serial += off; w.root_W += off;
         w.root_pp += off; w.path += (size_t)off * G::MAXPATH;
+        w.anc += (size_t)off * (d.max_plies + 2); w.anc_len += off; w.top_N += off;
         w.path_N += (size_t)off * G::MAXPATH; w.path_all += (size_t)off * G::MAXPATH; w.path_W += (size_t)off * G::MAXPATH; w.leaf_flags += off;
         w.leaf_state = (char *)d.leaf_state + (size_t)off * sizeof(typename G::State);
         w.leaf_game_id += off; w.leaf_serial += off; w.eval_value += off;
@@ -415,6 +417,7 @@ extern "C" int bb_create(const bb_config *cfg, bb_engine **out) {
     d.evaluator = cfg->evaluator;
     d.priors_ones = (cfg->mcts_kind == BB_MCTS_FIXED || cfg->evaluator == BB_EVAL_ROLLOUT) ? 1 : 0;
     d.salt_per_game = cfg->salt_per_game;
+    d.track_anc = (cfg->track_ancestors != 0 && cfg->game != BB_GAME_DRAGONCHESS) ? 1 : 0;
     d.max_games = cfg->max_games > 0 ? cfg->max_games : cfg->n_slots;
     e->cfg.max_games = d.max_games;
     d.c_puct = cfg->c_puct;
@@ -1254,6 +1257,49 @@ extern "C" int bb_move_roots(bb_engine *e, const int32_t *actions) {
         HIPCHK(hipGetLastError());
         HIPCHK(sync_all(e));
         return BB_OK;
+    });
+}
+
+extern "C" int bb_reset_roots(bb_engine *e) {
+    if (!e) return fail(BB_ERR_ARG, "null engine");
+    if (!e->dev.track_anc) return fail(BB_ERR_STATE, "this engine does not keep the ancestors of its roots (bb_config.track_ancestors)");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    GAME_SWITCH(e->cfg.game, {
+        if constexpr (G::GID == BB_GAME_DRAGONCHESS) {
+            return fail(BB_ERR_ARG, "ancestors are kept for the dense-action games");
+        } else {
+            k_reset_roots<G><<<nblk(e->dev.n_slots), 256, 0, e->stream>>>(e->dev);
+            HIPCHK(hipGetLastError());
+            HIPCHK(sync_all(e));
+            return BB_OK;
+        }
+    });
+}
+
+extern "C" int bb_node_view(bb_engine *e, int slot, int node, int32_t *child_node_out, int32_t *child_plays_out, float *child_value_out,
+                            void *state_out, int32_t *info_out) {
+    if (!e || slot < 0 || slot >= e->cfg.n_slots || !child_node_out || !child_plays_out || !child_value_out || !state_out || !info_out)
+        return fail(BB_ERR_ARG, "bad arguments");
+    if (node >= e->dev.node_cap) return fail(BB_ERR_ARG, "node %d out of range", node);
+    HIPCHK(hipSetDevice(e->cfg.device));
+    GAME_SWITCH(e->cfg.game, {
+        if constexpr (G::GID == BB_GAME_DRAGONCHESS) {
+            return fail(BB_ERR_ARG, "node views exist for the dense-action games");
+        } else {
+            DevBuf dc, dp, dv, ds, di;
+            if (dc.alloc(G::S * 4) || dp.alloc(G::S * 4) || dv.alloc(G::S * 4) || ds.alloc(sizeof(typename G::State)) || di.alloc(16)) return BB_ERR_HIP;
+            HIPCHK(sync_all(e));
+            k_node_view<G><<<1, 64, 0, e->stream>>>(e->dev, slot, node, (int32_t *)dc.p, (int32_t *)dp.p, (float *)dv.p,
+                                                    (typename G::State *)ds.p, (int32_t *)di.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(sync_all(e));
+            HIPCHK(hipMemcpy(child_node_out, dc.p, G::S * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(child_plays_out, dp.p, G::S * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(child_value_out, dv.p, G::S * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(state_out, ds.p, sizeof(typename G::State), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(info_out, di.p, 12, hipMemcpyDeviceToHost));
+            return BB_OK;
+        }
     });
 }
 

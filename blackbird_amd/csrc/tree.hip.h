@@ -88,6 +88,14 @@ struct TreeDev {
     int32_t *path_N, *path_all; // [n_slots][MAXPATH]  child.Plays of the chosen edge, sum(ChildPlays) of its node
     float *path_W;              // [n_slots][MAXPATH]  child.Value of the chosen edge
     int32_t *leaf_flags;        // [n_slots] flags word of the posted leaf | LEAF_RECORDED (0: posted by a kernel that records nothing)
+    // MCTS.ResetRoot (MCTS.py:214-225) walks Root back to its top-most ancestor, and _backProp (:238-258) recurses through every
+    // ancestor above the current root, so the statistics found there include every later simulation.  With track_anc (the
+    // FindMove front end's engines) a slot keeps the chain of (node, player, action) edges from the first root down to the
+    // current one, every backup also walks it, and bb_reset_roots puts the root back at its top.
+    int track_anc;
+    uint32_t *anc;      // [n_slots][max_plies + 2]  node<<6 | player<<4 | action, top-most first
+    int32_t *anc_len;   // [n_slots]
+    int32_t *top_N;     // [n_slots] Plays of the top-most ancestor (it has no parent edge to keep them in)
     // evaluator mailboxes
     void *leaf_state;       // [n_slots] packed state of the pending leaf
     uint32_t *leaf_game_id; // [n_slots]
@@ -226,8 +234,7 @@ __device__ __forceinline__ void backup_path(const TreeDev &d, int g, int lane, D
     constexpr int S = G::S;
     float vflip = 1.0f - v01;
     const uint32_t *path = d.path + (size_t)g * G::MAXPATH;
-    for (int k = lane; k < plen; k += S) {
-        uint32_t e = path[k];
+    auto edge = [&](uint32_t e) __attribute__((always_inline)) {
         int a = e & 15, pl = (e >> 4) & 3;
         DenseNode<G> *pn = pool + (e >> 6);
         int n = pn->N[a] + 1, all = pn->all + 1;
@@ -237,6 +244,13 @@ __device__ __forceinline__ void backup_path(const TreeDev &d, int g, int lane, D
         pn->Q[a] = __fdiv_rn(w, (float)n);
         pn->all = all;
         pn->sq = __dsqrt_rn(1.0 + (double)all);
+    };
+    for (int k = lane; k < plen; k += S) edge(path[k]);
+    if (d.track_anc) { // the reference's recursion does not stop at the current root: the edges above it (MCTS.py:252-258)
+        const uint32_t *anc = d.anc + (size_t)g * (d.max_plies + 2);
+        const int na = d.anc_len[g];
+        for (int k = lane; k < na; k += S) edge(anc[k]);
+        if (lane == 0) d.top_N[g] += 1;
     }
     if (lane == 0) {
         d.root_N[g] += 1;
@@ -665,6 +679,10 @@ __device__ __forceinline__ void advance_root(const TreeDev &d, int g, int lane, 
             d.root_N[g] = 0;
             d.root_W[g] = 0.f;
             d.root_pp[g] = 0;
+            if (d.track_anc) { // a new root without a parent
+                d.anc_len[g] = 0;
+                d.top_N[g] = 0;
+            }
         }
         return;
     }
@@ -690,10 +708,55 @@ __device__ __forceinline__ void advance_root(const TreeDev &d, int g, int lane, 
         new_st = pool[child & ~CHILD_TERM_BIT].st;
     }
     if (lane == 0) {
+        if (d.track_anc) {
+            if (child == 0 && cn == 0 && d.n_nodes[g] == 1) { // (the pool was exhausted above: the tree restarted)
+                d.anc_len[g] = 0;
+                d.top_N[g] = 0;
+            } else if (d.anc_len[g] < d.max_plies + 2) {
+                d.anc[(size_t)g * (d.max_plies + 2) + d.anc_len[g]] = ((uint32_t)d.root[g] << 6) | ((uint32_t)gs_player(st) << 4) | (uint32_t)a;
+                d.anc_len[g] += 1;
+            }
+        }
         d.root[g] = child & ~CHILD_TERM_BIT;
         d.root_N[g] = cn;
         d.root_W[g] = cw;
         d.root_pp[g] = (int8_t)gs_player(st);
+    }
+}
+
+// MCTS.ResetRoot (MCTS.py:214-225): the root goes back to its top-most ancestor; nothing is forgotten.
+template <class G>
+__global__ void __launch_bounds__(256) k_reset_roots(TreeDev d) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.n_slots || !d.track_anc || d.game_lid[g] < 0 || d.anc_len[g] <= 0) return;
+    d.root[g] = (int)(d.anc[(size_t)g * (d.max_plies + 2)] >> 6);
+    d.root_N[g] = d.top_N[g];
+    d.root_W[g] = 0.f;
+    d.root_pp[g] = 0;
+    d.anc_len[g] = 0;
+}
+
+// One node of a slot's tree for the host's Node view (MCTS.py:7-98): node < 0 = the root.  Per child slot i: the child's pool
+// index (CHILD_NONE where AddChildren would have made a Node that no simulation has reached yet), Plays, Value; the node's state,
+// flags and legal mask.
+template <class G>
+__global__ void __launch_bounds__(64) k_node_view(TreeDev d, int g, int node, int32_t *child_out, int32_t *plays_out, float *value_out,
+                                                   typename G::State *state_out, int32_t *info_out) {
+    using Node = DenseNode<G>;
+    const int lane = threadIdx.x;
+    if (lane >= G::S) return;
+    Node *pool = (Node *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
+    if (node < 0) node = d.root[g];
+    const Node *n = pool + node;
+    const bool exp = (n->flags & NODE_EXPANDED) != 0;
+    child_out[lane] = exp ? n->child[lane] : CHILD_NONE;
+    plays_out[lane] = exp ? n->N[lane] : 0;
+    value_out[lane] = exp ? n->W[lane] : 0.f;
+    if (lane == 0) {
+        *state_out = n->st;
+        info_out[0] = n->flags;
+        info_out[1] = (int32_t)(exp ? n->legal_mask : 0u);
+        info_out[2] = node;
     }
 }
 
@@ -731,6 +794,10 @@ __device__ __forceinline__ void reset_slot(const TreeDev &d, int g, int lid, con
     d.sim_serial[g] = 0;
     d.game_lid[g] = lid;
     if (d.leaf_flags) d.leaf_flags[g] = 0;
+    if (d.track_anc) {
+        d.anc_len[g] = 0;
+        d.top_N[g] = 0;
+    }
 }
 
 template <class G>

@@ -133,6 +133,9 @@ typedef struct {
     int32_t launch;        /* BB_LAUNCH_*: launch structure of bb_selfplay_step; 0 = AUTO (persistent kernels where the network
                               fits them).  The others exist for parity checks: every structure gives the same bits */
     int32_t general_net;   /* 1: run a 16-filter network through the launch-per-layer kernels of wider networks (parity checks) */
+    int32_t track_ancestors; /* 1: keep, per slot, the chain of edges from the first root to the current one and back every
+                              simulation up through it, as the reference's _backProp does (MCTS.py:238-258) -- what
+                              MCTS.ResetRoot (:214-225) needs; dense-action games */
 } bb_config;
 
 /* bb_config.net_form */
@@ -237,6 +240,16 @@ int bb_sample_moves(bb_engine *e, double temp, const double *u, int32_t *action_
 /* MoveRoot (MCTS.py:201-212, 260-282) by action id; actions[i] < 0 leaves slot i alone. */
 int bb_move_roots(bb_engine *e, const int32_t *actions);
 int bb_get_root_states(bb_engine *e, void *states_out);
+/* MCTS.ResetRoot (MCTS.py:214-225): every slot's root goes back to its top-most ancestor (the first position searched) with all
+ * statistics intact, including the simulations run from the positions below it (bb_config.track_ancestors; BB_ERR_STATE otherwise). */
+int bb_reset_roots(bb_engine *e);
+/* One node of a slot's tree, for a host-side Node view (MCTS.py:7-98: Children, Plays, Value, State): node < 0 = the root, else a pool
+ * index taken from an earlier view.  child_node_out / child_plays_out / child_value_out [S]: per child slot the child's pool index (-1:
+ * no simulation has reached it yet -- the reference's eager AddChildren would hold a Node with zero statistics there when the move is
+ * legal), its Plays and Value; state_out: the node's packed state; info_out[3]: flags (bit 0: expanded, bit 1: terminal), legal mask,
+ * the node's own pool index.  Dense-action games. */
+int bb_node_view(bb_engine *e, int slot, int node, int32_t *child_node_out, int32_t *child_plays_out, float *child_value_out,
+                 void *state_out, int32_t *info_out);
 
 /* Re-key the engine's random streams (Philox key `seed`; global id of local game 0).  The reference draws fresh numpy /
  * TensorFlow randomness on every GenerateTrainingSamples call (MCTS.py:336-338, NetworkFactory.py:176-180); a caller

@@ -315,6 +315,48 @@ def gen_mcts(key, tag, n_games, sims, seed, salt, temp=1.0, max_plies=10 ** 9, k
     print(key, tag, "mcts:", n_games, "games", len(rec["action"]), "moves")
 
 
+# ---- part 3b: ResetRoot and the Node graph one level down -------------------------------------
+def gen_resetroot(key, sims=40, moves=3, sims_after=25, salt=4100):
+    """MCTS.ResetRoot (MCTS.py:214-225) after `moves` rounds of FindMove + MoveRoot, all at temp 0 (the PUCT argmax: no random
+    draw): the statistics of the top-most ancestor and, through Children, of the nodes on the played line -- they include the
+    simulations run from the positions BELOW them, because _backProp (:238-258) recurses through every ancestor -- and then a
+    further FindMove from the first position on the tree that ResetRoot left."""
+    cls = GAMES[key]
+    m = RefModel(cls, salt, explorationRate=0.85, playLimit=sims)
+    s = cls()
+    acts = []
+    for _ in range(moves):
+        nxt, _v, _p = m.FindMove(s, 0)
+        legal = np.where(s.LegalActions() == 1)[0]
+        act = [int(a) for a in legal if m._applyAction(s, int(a)) == nxt][0]
+        acts.append(act)
+        s = nxt
+        m.MoveRoot(s)
+    m.ResetRoot()
+    out = {"actions": np.array(acts), "meta": np.array([sims, moves, sims_after, salt], dtype=np.int64)}
+    node = m.Root
+    for depth in range(moves + 1):   # the top-most ancestor, then down the played line
+        out[f"plays_{depth}"] = np.float64(node.Plays)
+        out[f"value_{depth}"] = np.float64(node.Value)
+        out[f"child_plays_{depth}"] = np.array(node.ChildPlays(), dtype=np.float64)
+        out[f"child_winrates_{depth}"] = np.array(node.ChildWinRates(), dtype=np.float64)
+        out[f"legal_{depth}"] = np.array(node.LegalActions, dtype=np.float64)
+        out[f"children_none_{depth}"] = np.array([c is None for c in node.Children]) if node.Children is not None else np.zeros(0, dtype=bool)
+        if depth < moves:
+            node = node.Children[acts[depth]]
+    s0 = cls()
+    nxt, v, prob = m.FindMove(s0, 0, playLimit=sims_after)
+    out["after_plays"] = np.float64(m.Root.Plays)
+    out["after_child_plays"] = np.array(m.Root.ChildPlays(), dtype=np.float64)
+    out["after_child_winrates"] = np.array(m.Root.ChildWinRates(), dtype=np.float64)
+    out["after_prob"] = np.array(prob, dtype=np.float64)
+    out["after_v"] = np.float64(v)
+    legal = np.where(s0.LegalActions() == 1)[0]
+    out["after_action"] = np.int64([int(a) for a in legal if m._applyAction(s0, int(a)) == nxt][0])
+    np.savez_compressed(os.path.join(OUT, f"resetroot_{key}.npz"), **out)
+    print(key, "resetroot:", acts, "top plays", out["plays_0"], "after", out["after_plays"])
+
+
 # ---- part 4: GenerateTrainingSamples end to end -------------------------------------------
 def gen_selfplay(key, n_games, sims, seed, salt, temp=1.0):
     cls = GAMES[key]
@@ -348,6 +390,7 @@ def gen_selfplay(key, n_games, sims, seed, salt, temp=1.0):
 
 
 PARTS = {
+    "resetroot": lambda: (gen_resetroot("c4"), gen_resetroot("ttt", sims=30, moves=2, sims_after=20, salt=4200)),
     "playouts": lambda: (gen_playouts("c4", 200, 11), gen_playouts("ttt", 200, 12),
                          gen_playouts("dc", 16, 13, max_plies=200)),
     "boards": lambda: (gen_random_boards("c4", 600, 21), gen_random_boards("ttt", 400, 22),

@@ -119,6 +119,55 @@ def test_findmove_api_golden(golden_dir, fname, monkeypatch):
                 m.DropRoot()
 
 
+@pytest.mark.parametrize("key", ["c4", "ttt"])
+def test_resetroot_and_children_golden(golden_dir, key):
+    """MCTS.ResetRoot (MCTS.py:214-225) and the Node graph below the root (MCTS.py:7-98), against the reference's own run
+    (tests/make_golden.py gen_resetroot): FindMove + MoveRoot a few times at temp 0, ResetRoot -- the top-most ancestor's
+    Plays are the sum of ALL simulations (the reference's _backProp walks through the ancestors above the current root) -- then
+    down the played line through Children, then another FindMove on the tree ResetRoot left."""
+    g = np.load(os.path.join(golden_dir, f"resetroot_{key}.npz"), allow_pickle=False)
+    cls = GAMES[key]
+    sims, moves, sims_after, salt = [int(x) for x in g["meta"]]
+    m = HashSearch(explorationRate=0.85, playLimit=sims)
+    m.salt = salt
+    s = cls()
+    for k in range(moves):
+        nxt, _v, _p = m.FindMove(s, 0)
+        want = s.Copy()
+        want.ApplyAction(int(g["actions"][k]))
+        assert nxt == want
+        s = nxt
+        m.MoveRoot(s)
+    m.ResetRoot()
+    node = m.Root
+    assert node.State == cls() and node.Parent is None
+    for depth in range(moves + 1):
+        assert node.Plays == g[f"plays_{depth}"], depth
+        assert np.float32(node.Value) == np.float32(g[f"value_{depth}"]), depth
+        assert np.array_equal(node.ChildPlays(), g[f"child_plays_{depth}"]), depth
+        assert np.array_equal(node.ChildWinRates(), g[f"child_winrates_{depth}"]), depth
+        assert np.array_equal(node.LegalActions, g[f"legal_{depth}"]), depth
+        assert [c is None for c in node.Children] == list(g[f"children_none_{depth}"]), depth
+        if depth < moves:
+            child = node.Children[int(g["actions"][depth])]
+            assert child.Parent is node
+            node = child
+    nxt, v, prob = m.FindMove(cls(), 0, playLimit=sims_after)
+    assert m.Root.Plays == g["after_plays"] and float(v) == float(g["after_v"])
+    assert np.array_equal(m.Root.ChildPlays(), g["after_child_plays"])
+    assert np.array_equal(m.Root.ChildWinRates(), g["after_child_winrates"])
+    assert np.array_equal(prob, g["after_prob"])
+    want = cls()
+    want.ApplyAction(int(g["after_action"]))
+    assert nxt == want
+    # ResetRoot on a tree that never moved, and on no tree at all, changes nothing
+    m.ResetRoot()
+    assert m.Root.Plays == g["after_plays"]
+    fresh = HashSearch(explorationRate=0.85, playLimit=4)
+    fresh.ResetRoot()
+    assert fresh.Root is None
+
+
 def test_findmove_errors():
     m = HashSearch(explorationRate=0.85)
     s = Connect4.BoardState()
