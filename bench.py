@@ -181,10 +181,9 @@ def profile_figures(key):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 p = json.load(f)
-            ev = float(p["evals_in_dispatch"])
             return {"file": "profiles/" + name, "commit": p.get("commit"),
-                    "mfma_bf16_flop_per_eval": p["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512.0 / ev,
-                    "hbm_bytes_per_eval": (p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0 / ev}
+                    "mfma_bf16_flop_per_eval": p["mfma_bf16_instructions_per_eval"] * 16384.0,
+                    "hbm_bytes_per_eval": p["hbm_bytes_per_eval"]}
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             continue
     return None

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/pmc_collect.sh <outdir> <bench args...>   (env such as BB_MEGA_QUEUE passes through)
+# usage: tools/pmc_collect.sh <outdir> <bench args...>   (tuning environment such as BB_QUEUE_NETW passes through)
 # Separate passes, counters only (--kernel-trace --pmc), as the MI355X guide prescribes.
 set -e
 OUT=$1; shift

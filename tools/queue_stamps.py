@@ -1,6 +1,5 @@
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["BB_MEGA_QUEUE"] = os.environ.get("QMODE", "1")
 import numpy as np
 from blackbird_amd import _lib, weights as W
 _lib.LIB_PATH = os.path.abspath(os.environ.get("BB_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbb_stamps.so")))

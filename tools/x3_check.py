@@ -1,18 +1,19 @@
 """Kernel-tuning aid: logits / value / policy of the engine's 16-filter network against the oracle's float32 restatement
-(max abs / relative difference), Connect4 and TicTacToe, random and perturbed weights.  BB_NET_X3=0 selects the float32
-MFMA path for comparison."""
+(max abs / relative difference), Connect4 and TicTacToe, random and perturbed weights.  F32=1 selects the float32
+MFMA path (bb_config.net_form) for comparison."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from blackbird_amd import _lib, weights as W
 from oracle import orc
+FORM = _lib.NET_FORM_F32 if os.environ.get("F32") == "1" else _lib.NET_FORM_AUTO
 for game in (_lib.GAME_CONNECT4, _lib.GAME_TICTACTOE):
     gi = _lib.game_info(game)
     for perturb in (False, True):
         for R in (4, 1, 0):
             w = W.init_weights(gi.C, 16, R, 16, gi.A, seed=11, perturb=perturb)
             flat = W.flatten(w)
-            eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)
+            eng = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET, net_form=FORM)
             eng.load_weights(flat)
             rng = np.random.RandomState(3)
             n = 203
@@ -33,7 +34,7 @@ game = _lib.GAME_DRAGONCHESS
 for R in (4, 1):
     w = W.init_weights(17, 16, R, 16, 4032, seed=13, perturb=True)
     flat = W.flatten(w)
-    eng = _lib.Engine(game, n_slots=2, sims_per_move=2, evaluator=_lib.EVAL_NET, max_plies=8)
+    eng = _lib.Engine(game, n_slots=2, sims_per_move=2, evaluator=_lib.EVAL_NET, max_plies=8, net_form=FORM)
     eng.load_weights(flat)
     rng = np.random.RandomState(5)
     n = 11
