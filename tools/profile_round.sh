@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_dc -- p
 echo "dc stats done"
 cd $REPO
 # PMC: the timed region as ONE launch (pmc_summary.py takes the longest dispatch), short settle / prefill to keep the passes short
-C2ARGS="--steps 6 --warmup 2 --prefill 16 --settle 8 --launches 1 --no-cpu-baseline --no-api"
+C2ARGS="--steps 8 --warmup 2 --prefill 16 --settle 4 --launches 1 --no-cpu-baseline --no-api"  # (the timed launch must be the longest dispatch: pmc_summary.py picks that one)
 bash tools/pmc_collect.sh gpurun_out/${TAG}_pmc_c2 $C2ARGS
 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_c2 k_selfplay_queue gpurun_out/${TAG}_pmc_c2/summary.json > /dev/null
 python3 tools/pmc_derive.py gpurun_out/${TAG}_pmc_c2/summary.json gpurun_out/${TAG}_queue_pmc_summary.json "kernel=k_selfplay_queue<Connect4,8,x3,12>" "command=bench.py $C2ARGS (timed-region dispatch)" "commit=$COMMIT" "passes_dir=gpurun_out/${TAG}_pmc_c2" > /dev/null
