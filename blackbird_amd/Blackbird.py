@@ -170,9 +170,14 @@ def GenerateTrainingSamples(model, nGames, temp):
     # game, as the reference issues them (Blackbird.py:267), inside a single sqlite transaction
     gi = _lib.game_info(game_cls.GAME_ID)
 
-    def blobs_of(r):
+    def planes_of(r):
+        """AsInputArray planes of a batch of records: one bb_game_encode call.  Made while the GPU is idle (between two launches):
+        a kernel launched beside a running persistent launch waits for it -- the launch fills every CU -- and the host work
+        queued behind that call would wait with it."""
         st = np.ascontiguousarray(r['state']).view(_lib.STATE_DTYPE[game_cls.GAME_ID]).reshape(len(r), -1)
-        planes = _lib.game_encode(game_cls.GAME_ID, st)
+        return _lib.game_encode(game_cls.GAME_ID, st)
+
+    def blobs_of(r, planes):
         tot = r['total'].astype(np.float64)
         if gi.dense:
             visits = r['visits'][:, :gi.A].astype(np.float64)
@@ -186,23 +191,23 @@ def GenerateTrainingSamples(model, nGames, temp):
 
     per = max(1, (1 << 22) // gi.A)  # chunks of whole games, about 32 MB of pi at a time (DragonChess: 4032 float64 per example)
 
-    def sink(rec, offs):
-        """Blobs + one PutGames per game for a batch of finished games (records compacted in game order)."""
+    def sink(rec, offs, planes):
+        """Blobs + one PutGames per game for a batch of finished games (records compacted in game order): host work only."""
         n, g = len(offs) - 1, 0
         while g < n:
             h = g + 1
             while h < n and offs[h + 1] - offs[g] <= per:
                 h += 1
-            blobs = blobs_of(rec[offs[g]:offs[h]])
+            blobs = blobs_of(rec[offs[g]:offs[h]], planes[offs[g]:offs[h]])
             for k in range(g, h):
                 model.Conn.PutGames(model.Name, model.Version, game_cls.GameType,
                                     blobs[offs[k] - offs[g]:offs[k + 1] - offs[g]])
             g = h
 
-    # The host side runs BESIDE the GPU: while a launch plays on, the games that finished during the previous ones are fetched
-    # (compacted on the device, one copy), serialised and stored.  The engine refills a finished game's slot with the next game
-    # id by itself, so nGames may exceed the slot count.  (Round 2 serialised everything after the last game had ended: the
-    # caller saw 60 % of the engine's games/s.)
+    # The host side runs BESIDE the GPU: between two launches (GPU idle) the games that finished during the last one are fetched
+    # (compacted on the device, one copy) and their planes encoded; while the next launch plays on they are serialised and
+    # stored.  The engine refills a finished game's slot with the next game id by itself, so nGames may exceed the slot count.
+    # (Round 2 serialised everything after the last game had ended: the caller saw 60 % of the engine's games/s.)
     deferred = getattr(model.Conn, 'Deferred', None)
     ctx = deferred() if deferred is not None else None
     if ctx is not None:
@@ -223,7 +228,7 @@ def GenerateTrainingSamples(model, nGames, temp):
             if len(new):
                 seen[new] = True
                 rec, offs, _win = eng.fetch_games(new, int(hdr[new, 0].sum()))
-                pending = (rec, offs)
+                pending = (rec, offs, planes_of(rec))
             if seen.all():
                 break
         if pending is not None:
