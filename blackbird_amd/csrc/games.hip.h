@@ -80,6 +80,7 @@ struct GridGame {
     static constexpr int GID = GID_; // BB_GAME_*
     static constexpr int MAXPATH = H_ * W_ + 2;
     static constexpr bool DROP = (GID_ == 0); // Connect4: pieces fall
+    static constexpr bool CELL_BF16 = false;  // (DragonChess: encode_cell_bf16)
     using State = GridState;
 
     BB_HD static uint64_t board_mask() {
@@ -204,6 +205,7 @@ static_assert(sizeof(DCState) == 80, "packed DragonChess state is 80 bytes");
 struct DragonChess {
     static constexpr int H = 8, W = 8, C = 17, A = 4032, S = 144, GID = 2;
     static constexpr int MAXPATH = 128;
+    static constexpr bool CELL_BF16 = true;
     using State = DCState;
 
     BB_HD static State initial() { // fen 'rnbqkbnr/pppppppp/8/8/8/8/3PPP2/4K3 w kq' (DragonChess.py:36-60)
@@ -451,5 +453,19 @@ struct DragonChess {
         out[14] = s.castle[2];
         out[15] = s.castle[3];
         out[16] = (s.player == 1 && s.prev == 1) ? 1 : 0;
+    }
+    // The same cell as the 32 bf16 values the split-operand first conv reads (17 planes + zero padding), two per word,
+    // without the 12-way switch (a divergent wave walks every case): the piece plane from a nibble table indexed by code + 6
+    // (15 = empty square), bf16 1.0 = 0x3F80.  tests/test_gpu_net.py compares the network on encode_cell's planes.
+    __device__ __forceinline__ static void encode_cell_bf16(const State &s, int r, int c, uint32_t out[16]) {
+        const int v = s.b[r * 8 + c];
+        const int plane = (int)((0x82640AFB15739ull >> (4 * (v + 6))) & 15);
+        const uint32_t one = 0x3F80u << (16 * (plane & 1));
+        for (int j = 0; j < 6; j++) out[j] = (plane >> 1) == j ? one : 0u;
+        auto bf = [](int x) { return __builtin_bit_cast(uint32_t, (float)x) >> 16; };
+        out[6] = bf(s.castle[0]) | (bf(s.castle[1]) << 16);
+        out[7] = bf(s.castle[2]) | (bf(s.castle[3]) << 16);
+        out[8] = (s.player == 1 && s.prev == 1) ? 0x3F80u : 0u;
+        for (int j = 9; j < 16; j++) out[j] = 0u;
     }
 };

@@ -171,6 +171,11 @@ __device__ __forceinline__ void x3_split4(const f32x4 y, u32x2 &p1, u32x2 &p2, u
 // tile t's 27 MFMAs execute (a bf16 MFMA leaves 8 of its 16 cycles to the wave's vector instructions).
 // HEADS_OUT (persistent kernel): the wave stops after the three pooled head activations (R, R0, R1) and hands them to the
 // caller's `pooled_out` -- the value / policy tails (head_one) then run on the tree wave that picks the result up.
+#ifdef BB_STAMPS_NET_SUB
+#define NSUB(i) NSTAMP(i) // prologue split (diagnostic): 5 = loads issued + zero fill, 6 = state to LDS, 7 = planes; 0 = the rest
+#else
+#define NSUB(i) do {} while (0)
+#endif
 #define X3_DBG(bit) ND_DBG(bit) // ablation switches of the diagnostic build (bb_timing_net; results are wrong when set)
 template <class G, bool WLDS, bool LEAN = false, bool PP = false, bool HEADS_OUT = false>
 __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, int n, int pos0, const int *slot_list,
@@ -200,7 +205,11 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
 #endif
 
     // ---- prologue: the board, the first conv's operands, zero fill -------------------------------------------------
-    const typename G::State my_state = planes ? G::initial() : states[OI(live ? pos0 : 0)];
+    // (PP = the one-wave-per-game kernel: its leaf positions already live in LDS (DCShadow), read them where they are)
+    const typename G::State *sst_in = sst;
+    typename G::State my_state;
+    if constexpr (PP) sst_in = as_lds(&states[OI(live ? pos0 : 0)]);
+    else my_state = planes ? G::initial() : states[OI(live ? pos0 : 0)];
     const unsigned char *w0p = x3.w0;
     bf16x8 w0a[WIDE_IN ? 27 : 3]; // wide input: [tap][plane], all requested now (L2), consumed tap by tap
     bf16x8 w0b;                   // narrow input: tap 8's three weight planes side by side in one K = 32 operand
@@ -214,32 +223,58 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     }
     const f32x4 bias0 = *(const f32x4 *)(nd.epi + 4 * g), scale0 = *(const f32x4 *)(nd.epi + 16 + 4 * g),
                 shift0 = *(const f32x4 *)(nd.epi + 32 + 4 * g);
+    NSUB(5);
     if (zero_lds) {
         u32x4 z = {0u, 0u, 0u, 0u};
-        for (int i = lane; i < (PP ? XG::WAVE_BYTES_PP : XG::WAVE_BYTES) / 16; i += 64) ((u32x4 *)wl)[i] = z;
+        if constexpr (PP) {
+            // every pixel slot is rewritten by each evaluation (input planes, then the first conv's three planes, every layer
+            // after it); only the halo must read as zero: row 0, the first slot of rows 1 .. H, everything from row H + 1 on --
+            // in both buffers, 16 bytes per lane and store
+            constexpr int NHALO = RS + XG::H + (XG::SLOTS - (XG::H + 1) * RS), CH = SB / 16;
+            for (int i = lane; i < 2 * NHALO * CH; i += 64) {
+                const int buf = i >= NHALO * CH, j = i - buf * NHALO * CH, hs = j / CH, c = j - hs * CH;
+                const int slot = hs < RS ? hs : hs < RS + XG::H ? (hs - RS + 1) * RS : (XG::H + 1) * RS + (hs - RS - XG::H);
+                *(u32x4 *)(wl + buf * XG::X_B + slot * SB + c * 16) = z;
+            }
+        } else {
+            for (int i = lane; i < XG::WAVE_BYTES / 16; i += 64) ((u32x4 *)wl)[i] = z;
+        }
     }
     wave_lds_handover();
-    if (!planes && lane == 0) *sst = my_state;
-    wave_lds_handover();
+    NSUB(6);
+    if constexpr (!PP) {
+        if (!planes && lane == 0) *sst = my_state;
+        wave_lds_handover();
+    }
     if constexpr (WIDE_IN) {
         if (lane < HW && live) { // input planes of pixel `lane`: 32 x bf16 in the first 64 B of its X slot
             const int y = lane / W, x = lane % W;
-            int8_t v[CIN];
-            if (planes) {
-                const int8_t *src = planes + ((size_t)pos0 * HW + lane) * CIN;
-#pragma unroll
-                for (int c = 0; c < CIN; c++) v[c] = src[c];
-            } else {
-                G::encode_cell(*sst, y, x, v);
+            uint32_t pk[16]; // 32 bf16 values, two per word
+            bool packed = false;
+            if constexpr (G::CELL_BF16) {
+                if (!planes) {
+                    G::encode_cell_bf16(*sst_in, y, x, pk);
+                    packed = true;
+                }
             }
-            unsigned b[32];
+            if (!packed) {
+                int8_t v[CIN];
+                if (planes) {
+                    const int8_t *src = planes + ((size_t)pos0 * HW + lane) * CIN;
 #pragma unroll
-            for (int c = 0; c < 32; c++) b[c] = c < CIN ? __float_as_uint((float)v[c]) >> 16 : 0u;
+                    for (int c = 0; c < CIN; c++) v[c] = src[c];
+                } else {
+                    G::encode_cell(*sst_in, y, x, v);
+                }
+                unsigned b[32];
+#pragma unroll
+                for (int c = 0; c < 32; c++) b[c] = c < CIN ? __float_as_uint((float)v[c]) >> 16 : 0u;
+#pragma unroll
+                for (int k = 0; k < 16; k++) pk[k] = b[2 * k] | (b[2 * k + 1] << 16);
+            }
             unsigned char *dst = X + ((y + 1) * RS + (x + 1)) * SB;
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                *(u32x4 *)(dst + 16 * k) = u32x4{b[8 * k] | (b[8 * k + 1] << 16), b[8 * k + 2] | (b[8 * k + 3] << 16),
-                                                 b[8 * k + 4] | (b[8 * k + 5] << 16), b[8 * k + 6] | (b[8 * k + 7] << 16)};
+            for (int k = 0; k < 4; k++) *(u32x4 *)(dst + 16 * k) = u32x4{pk[4 * k], pk[4 * k + 1], pk[4 * k + 2], pk[4 * k + 3]};
         }
     } else
     if (lane < HW && live) { // input planes of pixel `lane`: 4 x bf16 (the int8 plane values are exact in bf16) in the first 8 B of its slot
@@ -251,7 +286,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             for (int c = 0; c < CIN; c++) v[c] = src[c];
         } else {
             int8_t e[CIN];
-            G::encode_cell(*sst, y, x, e);
+            G::encode_cell(*sst_in, y, x, e);
 #pragma unroll
             for (int c = 0; c < CIN; c++) v[c] = e[c];
         }
@@ -260,6 +295,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
         for (int c = 0; c < 4; c++) b[c] = __float_as_uint((float)v[c]) >> 16;
         *(u32x2 *)(X + ((y + 1) * RS + (x + 1)) * SB) = u32x2{b[0] | (b[1] << 16), b[2] | (b[3] << 16)};
     }
+    NSUB(7);
     // ---- per-tile addressing (bytes; X3Geom: tile_slot, swz).  Offsets are biased by the window's top-left tap, so every
     // tap of a row slice is a non-negative immediate on one address register.
     // A tile's slots are the previous tile's + TS bytes (the swizzle repeats every 8 slots), so one address register per

@@ -220,6 +220,37 @@ __device__ __forceinline__ double puct_score(double q, double cPi, double sq, in
     double u = q + __ddiv_rn(cPi * sq, 1.0 + (double)Ni);
     return legal ? u : -1.0;
 }
+// The same argmax without the float64 arithmetic wherever float32 can already tell: BB_PUCT_FILTER.
+//   uf = fl32(q + fl32(cP * sq) * rcp32(1 + N)) differs from the float64 score u by at most 2^-21 * u (q, cP, sq >= 0: one rounding
+//   of the product, one ulp of v_rcp_f32, one rounding of the fma), and every u is <= the group's true maximum <= mf + that.
+//   A lane whose uf lies more than 2^-18 * mf under the float32 maximum mf therefore cannot hold the float64 maximum; if exactly
+//   one lane of every group of the wave survives, it is the float64 argmax (first-maximum rule included: there is no tie).
+//   Otherwise -- near ties, exact ties, all-zero scores -- the whole wave takes the float64 path.  The float64 divide, the
+//   v_max_f64 butterflies and the 64-bit DPP moves (8- to 16-cycle instructions) leave the common path of a tree level.
+#ifndef BB_PUCT_FILTER
+#define BB_PUCT_FILTER 1
+#endif
+template <int S>
+__device__ __forceinline__ int grp_argmax_puct(float qf, double cPi, double sq, int Ni, bool legal, int &payload) {
+#if BB_PUCT_FILTER
+    const float num = (float)(cPi * sq);
+    const float uf = legal ? __builtin_fmaf(num, __builtin_amdgcn_rcpf((float)(Ni + 1)), qf) : -1.0f;
+    float mf = uf;
+    mf = __builtin_fmaxf(mf, __int_as_float(dpp_step_i<0>(__float_as_int(mf))));
+    mf = __builtin_fmaxf(mf, __int_as_float(dpp_step_i<1>(__float_as_int(mf))));
+    mf = __builtin_fmaxf(mf, __int_as_float(dpp_step_i<2>(__float_as_int(mf))));
+    if (S == 16) mf = __builtin_fmaxf(mf, __int_as_float(dpp_step_i<3>(__float_as_int(mf))));
+    const unsigned long long cand = __ballot(uf >= mf - mf * 0x1p-18f && uf >= 0.0f);
+    const int l64 = (int)__lane_id();
+    const unsigned grp = (unsigned)(cand >> (l64 & ~(S - 1))) & ((1u << S) - 1u);
+    if (__ballot((grp & (grp - 1u)) != 0u || grp == 0u) == 0ull) { // one candidate in every group of the wave
+        const int win = __ffs(grp) - 1;
+        payload = __shfl(payload, win, S);
+        return win;
+    }
+#endif
+    return grp_argmax<S>(puct_score((double)qf, cPi, sq, Ni, legal), 0, payload);
+}
 // Node.WinRate() of a child: float32 division for float32 evaluators, Python-float division for rollouts
 __device__ __forceinline__ double child_q(const TreeDev &d, float Qi, float Wi, int Ni) {
     if (d.evaluator != 2) return (double)Qi;
@@ -1101,9 +1132,9 @@ __device__ bool async_game(const TreeDev &d, int g, int lane
                 if (best >= 0) pf_touch = ((const int *)(pool + (bchild & ~CHILD_TERM_BIT)))[lane * 8];
             }
 #endif
-            double u = puct_score(child_q(d, Qi, 0.f, Ni), cPi, sq, Ni, lane < A && ((mask >> lane) & 1u));
+            // (float32 evaluators only reach this kernel: a child's WinRate is its float32 Q, child_q)
             int child = ci;
-            int a = grp_argmax<S>(u, lane, child);
+            int a = grp_argmax_puct<S>(Qi, cPi, sq, Ni, lane < A && ((mask >> lane) & 1u), child);
 #if defined(BB_STAMPS_LIGHT) && !defined(BB_STAMPS_LIGHT2)
             asm volatile("" ::"v"(a), "v"(child));
             lt_puct += (int)clock64() - lt_b;

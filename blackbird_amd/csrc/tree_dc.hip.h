@@ -588,19 +588,51 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
         }
         QS(q_edge);
 #endif
-        for (int k = lane; k < n_edges; k += 64) {
-            size_t e = base + k;
-            int Ni = E.e[e].N;
-            double q = child_q(d, E.e[e].Q, rollout ? E.e[e].W : 0.f, Ni);
-            double u = puct_score(q, E.e[e].cP, sq, Ni, true);
-            if (bi < 0 || u > bu) {
-                bu = u;
-                bi = k;
-                bchild = E.e[e].child;
-                bact = E.e[e].act;
+        bool picked = false;
+#if BB_PUCT_FILTER
+        if (!rollout) { // float32 scores first (tree.hip.h grp_argmax_puct: bound and argument); a lane keeps its best and its runner-up
+            float b1 = -1.0f, b2 = -1.0f;
+            for (int k = lane; k < n_edges; k += 64) {
+                size_t e = base + k;
+                const float uf = __builtin_fmaf((float)(E.e[e].cP * sq), __builtin_amdgcn_rcpf((float)(E.e[e].N + 1)), E.e[e].Q);
+                if (uf > b1) {
+                    b2 = b1;
+                    b1 = uf;
+                    bi = k;
+                    bchild = E.e[e].child;
+                    bact = E.e[e].act;
+                } else {
+                    b2 = __builtin_fmaxf(b2, uf);
+                }
+            }
+            const float mf = wave_max_f32(b1), thr = mf - mf * 0x1p-18f;
+            const unsigned long long cand = __ballot(bi >= 0 && b1 >= thr), amb = __ballot(bi >= 0 && b2 >= thr);
+            if (amb == 0ull && cand != 0ull && (cand & (cand - 1ull)) == 0ull) { // one edge of the node can hold the float64 maximum
+                const int w = __builtin_amdgcn_readfirstlane(__ffsll((long long)cand) - 1);
+                bi = __builtin_amdgcn_readlane(bi, w);
+                bchild = __builtin_amdgcn_readlane(bchild, w);
+                bact = __builtin_amdgcn_readlane(bact, w);
+                picked = true;
+            } else {
+                bi = -1;
             }
         }
-        wave_argmax(bu, bi, bchild, bact);
+#endif
+        if (!picked) {
+            for (int k = lane; k < n_edges; k += 64) {
+                size_t e = base + k;
+                int Ni = E.e[e].N;
+                double q = child_q(d, E.e[e].Q, rollout ? E.e[e].W : 0.f, Ni);
+                double u = puct_score(q, E.e[e].cP, sq, Ni, true);
+                if (bi < 0 || u > bu) {
+                    bu = u;
+                    bi = k;
+                    bchild = E.e[e].child;
+                    bact = E.e[e].act;
+                }
+            }
+            wave_argmax(bu, bi, bchild, bact);
+        }
         QS(q_cmp);
         if (depth >= DragonChess::MAXPATH) { overflow = 1; if (!have_st) st = dc_lane_load(&node->st, lane); break; }
         int child = bchild;
