@@ -35,8 +35,12 @@ struct alignas(16) DCEdge {
     int32_t child;  // node index | CHILD_TERM_BIT, or CHILD_NONE
     double cP;      // c_puct * prior
     uint16_t act;   // action id
-    uint16_t pad0;
-    uint32_t pad1;
+    // Where the child's own edges are (0, 0 until it has been expanded -- a node is expanded once, so the pair never changes
+    // afterwards): a copy of child.n_edges / child.edge_off.  The descent requests the child's edges together with the
+    // child's node row instead of after it -- one memory round trip per tree level instead of two.  Only a hint: the node
+    // row stays the authority (dc_phase_select checks the pair against it and otherwise loads the edges the ordinary way).
+    uint16_t c_edges;
+    uint32_t c_off;
 };
 static_assert(sizeof(DCEdge) == 32, "DragonChess edge record is half a cache line");
 
@@ -357,6 +361,8 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
             E.e[e].W = 0.f;
             E.e[e].child = CHILD_NONE;
             E.e[e].cP = priors ? d.c_puct * __ddiv_rn((double)myp[i], tot) : d.c_puct * 1.0;
+            E.e[e].c_edges = 0;
+            E.e[e].c_off = 0u;
         }
     if (lane == 0) {
         node->flags = node_flags | NODE_EXPANDED;
@@ -432,9 +438,14 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
 #endif
     if (pend_exp) {
         uint32_t gid = d.first_game_id + (uint32_t)lid;
+        const int used0 = used;
         if (!dc_expand(d, E, g, node, st_player, leaf_st->b, hl ? nullptr : d.eval_policy + (size_t)g * 4032, hl, gid,
-                       lane, lds, leaf, leaf_flags, used) && lane == 0)
-            d.ctr[(size_t)g * 8 + 6] += 1;
+                       lane, lds, leaf, leaf_flags, used)) {
+            if (lane == 0) d.ctr[(size_t)g * 8 + 6] += 1;
+        } else if (plen > 0 && plen <= 64 && lane == plen - 1 && used - used0 <= 0xFFFF) {
+            E.e[my_e].c_edges = (uint16_t)(used - used0); // the edge that leads to the leaf (DCEdge::c_edges)
+            E.e[my_e].c_off = (uint32_t)used0;
+        }
     }
     int player = st_player, prev = st_prev;
     float v01;
@@ -506,6 +517,40 @@ __device__ __forceinline__ int dc_create_child(const TreeDev &d, const DCEdges &
     return word;
 }
 
+// A node row's head and an edge record through the global address space, as two 16-byte loads each
+struct DCNodeHead {
+    int flags, n_edges, edge_off;
+    double sq;
+};
+__device__ __forceinline__ DCNodeHead dc_head_load(const DCNode *p) {
+    typedef const __attribute__((address_space(1))) u32x4 *GP;
+    const GP q = (GP)(const void *)p;
+    const u32x4 a = q[0], b = q[1];
+    DCNodeHead h;
+    h.flags = (int)a[0];
+    h.n_edges = (int)a[1];
+    h.edge_off = (int)a[2];
+    h.sq = __longlong_as_double((long long)(((unsigned long long)b[1] << 32) | b[0]));
+    return h;
+}
+__device__ __forceinline__ DCEdge dc_edge_load(const DCEdge *p) {
+    typedef const __attribute__((address_space(1))) u32x4 *GP;
+    const GP q = (GP)(const void *)p;
+    const u32x4 a = q[0], b = q[1];
+    DCEdge r;
+    r.N = (int)a[0];
+    r.Q = __uint_as_float(a[1]);
+    r.W = __uint_as_float(a[2]);
+    r.child = (int)a[3];
+    r.cP = __longlong_as_double((long long)(((unsigned long long)b[1] << 32) | b[0]));
+    r.act = (uint16_t)(b[2] & 0xffffu);
+    r.c_edges = (uint16_t)(b[2] >> 16);
+    r.c_off = b[3];
+    return r;
+}
+static_assert(offsetof(DCNode, sq) == 16 && offsetof(DCEdge, cP) == 16 && offsetof(DCEdge, act) == 24 &&
+              offsetof(DCEdge, c_edges) == 26 && offsetof(DCEdge, c_off) == 28, "dc_head_load / dc_edge_load read these layouts");
+
 __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int lane, float *lds) {
     const int lid = d.game_lid[g], sims_left = d.sims_left[g];
     int cur = d.root[g];
@@ -543,13 +588,22 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
     int flags = 0;
     bool have = false;
     uint32_t my_pn = 0, my_pe = 0;
+    int hint_n = 0;         // DCEdge::c_edges / c_off of the edge just taken: where this node's edges are, if it has any yet
+    uint32_t hint_off = 0u;
+    const size_t ebase = (size_t)(g + d.pool_g0) * E.edge_cap;
     for (int it = 0;; it++) {
         DCNode *node = pool + cur;
-        if (!have) {
-            flags = node->flags;
-        }
-        int n_edges = node->n_edges, edge_off = node->edge_off;
-        double sq = node->sq;
+        // This lane's edge of the first pass, requested TOGETHER with the node row (the hint says where the edges are): both
+        // loads are unconditional -- lanes past the hint read its last edge, no hint reads the pool's first edge -- because a
+        // load inside a divergent branch is waited for at the end of that branch, which would put the two round trips back in
+        // sequence.  (Global-address-space loads: a flat load also ties up lgkmcnt.)
+        const int hl = min(lane, max(hint_n, 1) - 1);
+        DCEdge pre = dc_edge_load(E.e + ebase + hint_off + hl);
+        const DCNodeHead hd = dc_head_load(node);
+        if (!have) flags = hd.flags;
+        int n_edges = hd.n_edges, edge_off = hd.edge_off;
+        double sq = hd.sq;
+        const bool pre_ok = hint_n > 0 && hint_n == n_edges && hint_off == (uint32_t)edge_off;
 #ifdef BB_STAMPS
         asm volatile("" ::"v"(n_edges), "v"(edge_off), "v"(sq), "v"(flags));
         if (it == 0) QS(q_pre); else QS(q_rest);
@@ -580,27 +634,29 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
         // PUCT over the node's edges, 64 per pass
         double bu = -1.0;
         int bi = -1, bchild = CHILD_NONE, bact = 0;
-        size_t base = (size_t)(g + d.pool_g0) * E.edge_cap + edge_off;
+        size_t base = ebase + edge_off;
+        if (!pre_ok) pre = dc_edge_load(E.e + base + min(lane, max(n_edges, 1) - 1)); // (root, a node whose incoming edge carries no hint)
 #ifdef BB_STAMPS
-        if (lane < n_edges) {
-            DCEdge probe = E.e[base + lane];
-            asm volatile("" ::"v"(probe.N), "v"(probe.cP));
-        }
+        asm volatile("" ::"v"(pre.N), "v"(pre.cP));
         QS(q_edge);
 #endif
+        int bhint = 0; // the winner's c_edges, c_off
+        uint32_t bhoff = 0u;
         bool picked = false;
 #if BB_PUCT_FILTER
         if (!rollout) { // float32 scores first (tree.hip.h grp_argmax_puct: bound and argument); a lane keeps its best and its runner-up
             float b1 = -1.0f, b2 = -1.0f;
             for (int k = lane; k < n_edges; k += 64) {
-                size_t e = base + k;
-                const float uf = __builtin_fmaf((float)(E.e[e].cP * sq), __builtin_amdgcn_rcpf((float)(E.e[e].N + 1)), E.e[e].Q);
+                const DCEdge r = k < 64 ? pre : E.e[base + k];
+                const float uf = __builtin_fmaf((float)(r.cP * sq), __builtin_amdgcn_rcpf((float)(r.N + 1)), r.Q);
                 if (uf > b1) {
                     b2 = b1;
                     b1 = uf;
                     bi = k;
-                    bchild = E.e[e].child;
-                    bact = E.e[e].act;
+                    bchild = r.child;
+                    bact = r.act;
+                    bhint = r.c_edges;
+                    bhoff = r.c_off;
                 } else {
                     b2 = __builtin_fmaxf(b2, uf);
                 }
@@ -612,6 +668,8 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
                 bi = __builtin_amdgcn_readlane(bi, w);
                 bchild = __builtin_amdgcn_readlane(bchild, w);
                 bact = __builtin_amdgcn_readlane(bact, w);
+                bhint = __builtin_amdgcn_readlane(bhint, w);
+                bhoff = (uint32_t)__builtin_amdgcn_readlane((int)bhoff, w);
                 picked = true;
             } else {
                 bi = -1;
@@ -620,19 +678,22 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
 #endif
         if (!picked) {
             for (int k = lane; k < n_edges; k += 64) {
-                size_t e = base + k;
-                int Ni = E.e[e].N;
-                double q = child_q(d, E.e[e].Q, rollout ? E.e[e].W : 0.f, Ni);
-                double u = puct_score(q, E.e[e].cP, sq, Ni, true);
+                const DCEdge r = k < 64 ? pre : E.e[base + k];
+                int Ni = r.N;
+                double q = child_q(d, r.Q, rollout ? r.W : 0.f, Ni);
+                double u = puct_score(q, r.cP, sq, Ni, true);
                 if (bi < 0 || u > bu) {
                     bu = u;
                     bi = k;
-                    bchild = E.e[e].child;
-                    bact = E.e[e].act;
+                    bchild = r.child;
+                    bact = r.act;
                 }
             }
             wave_argmax(bu, bi, bchild, bact);
+            bhint = 0; // (rare path: the next level loads its edges after its node row)
         }
+        hint_n = bhint;
+        hint_off = bhoff;
         QS(q_cmp);
         if (depth >= DragonChess::MAXPATH) { overflow = 1; if (!have_st) st = dc_lane_load(&node->st, lane); break; }
         int child = bchild;
@@ -650,6 +711,7 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
             }
         }
         if (child == CHILD_NONE) { // materialise the child: _applyAction on the parent's position, Winner(lastAction)
+            hint_n = 0;
             st = dc_lane_load(&node->st, lane);
             if (nn >= d.node_cap) { overflow = 1; break; } // pool exhausted: the parent's position stands in as the leaf
             const int w = dc_lane_apply(st, bact, lane);
