@@ -21,9 +21,9 @@ __device__ __attribute__((noinline)) void dc_fused_tree(const TreeDev &d_, const
     const DCEdges &E = *as_lds(&E_);
     tl = as_lds(tl);
     hl = as_lds(hl);
-    dc_phase_apply(d, E, g, lane, tl, hl);
+    dc_phase_apply<true>(d, E, g, lane, tl, hl);
     __threadfence_block();
-    dc_phase_select(d, E, g, lane, tl);
+    dc_phase_select<true>(d, E, g, lane, tl);
     __threadfence_block();
 }
 // The network for the wave's own leaf.  Nothing 4032-wide leaves the wave: the policy head is reduced to (R0, R1, max,
@@ -48,7 +48,7 @@ __device__ __attribute__((noinline)) void dc_fused_apply(const TreeDev &d_, cons
     const DCEdges &E = *as_lds(&E_);
     tl = as_lds(tl);
     hl = as_lds(hl);
-    dc_phase_apply(d, E, g, lane, tl, hl);
+    dc_phase_apply<true>(d, E, g, lane, tl, hl);
     __threadfence_block();
 }
 // The same on the bf16 matrix pipe (net_x3.hip.h): every operand plane of the tower streams from L2 a layer ahead (this

@@ -384,6 +384,14 @@ __device__ bool dc_expand(const TreeDev &d, const DCEdges &E, int g, DCNode *nod
     return true;
 }
 
+// SH = the per-game control state (TreeDev's [n_slots] arrays, the paths, DCEdges::used) lives in the caller's LDS
+// (mega_dc.hip.h: DCShadow) -- tell the compiler, or every access is a flat instruction (games.hip.h: as_lds)
+template <bool SH, class T>
+__device__ __forceinline__ T *dc_ctl(T *p) {
+    if constexpr (SH) return as_lds(p);
+    else return p;
+}
+template <bool SH = false>
 __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int lane, float *lds, const DCHeadLocal *hl = nullptr) {
     // One wave per game and one wave per SIMD: this step is a chain of dependent HBM round trips (2-3 us each on
     // these sparsely touched pools), so every word that does not depend on another load is requested up front, and
@@ -391,22 +399,22 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
 #ifdef BB_STAMPS
     const long long a_in = clock64();
 #endif
-    const int leaf = d.pend_leaf[g];
-    const int pend_exp = d.pend_expand[g];
-    const float v = hl ? hl->h.value : d.eval_value[g];
-    const int plen = d.path_len[g];
-    const int lid = d.game_lid[g];
-    const uint32_t *pn = d.path + (size_t)g * DragonChess::MAXPATH;
-    const uint32_t *pe = E.path_edge + (size_t)g * DragonChess::MAXPATH;
+    const int leaf = dc_ctl<SH>(d.pend_leaf)[g];
+    const int pend_exp = dc_ctl<SH>(d.pend_expand)[g];
+    const float v = hl ? hl->h.value : dc_ctl<SH>(d.eval_value)[g];
+    const int plen = dc_ctl<SH>(d.path_len)[g];
+    const int lid = dc_ctl<SH>(d.game_lid)[g];
+    const uint32_t *pn = dc_ctl<SH>(d.path) + (size_t)g * DragonChess::MAXPATH;
+    const uint32_t *pe = dc_ctl<SH>(E.path_edge) + (size_t)g * DragonChess::MAXPATH;
     const uint32_t pn0 = pn[lane], pe0 = pe[lane]; // lane < 64 <= MAXPATH: in bounds whatever the path length
     int root_n = 0, pp = 0;
     float root_w = 0.f;
     if (lane == 0) {
-        root_n = d.root_N[g];
-        pp = d.root_pp[g];
-        root_w = d.root_W[g];
+        root_n = dc_ctl<SH>(d.root_N)[g];
+        pp = dc_ctl<SH>(d.root_pp)[g];
+        root_w = dc_ctl<SH>(d.root_W)[g];
     }
-    int used = E.used[g];
+    int used = dc_ctl<SH>(E.used)[g];
     if (leaf < 0) return;
 #ifdef BB_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -414,7 +422,7 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
 #endif
     DCNode *pool = (DCNode *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
     DCNode *node = pool + leaf;
-    const DCState *leaf_st = (const DCState *)d.leaf_state + g;
+    const DCState *leaf_st = dc_ctl<SH>((const DCState *)d.leaf_state) + g;
     const int st_player = leaf_st->player, st_prev = leaf_st->prev;
     // the path's statistics (edges and nodes above the leaf: the expansion below touches none of them)
     const bool on_path = lane < plen;
@@ -441,7 +449,7 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
         const int used0 = used;
         if (!dc_expand(d, E, g, node, st_player, leaf_st->b, hl ? nullptr : d.eval_policy + (size_t)g * 4032, hl, gid,
                        lane, lds, leaf, leaf_flags, used)) {
-            if (lane == 0) d.ctr[(size_t)g * 8 + 6] += 1;
+            if (lane == 0) dc_ctl<SH>(d.ctr)[(size_t)g * 8 + 6] += 1;
         } else if (plen > 0 && plen <= 64 && lane == plen - 1 && used - used0 <= 0xFFFF) {
             E.e[my_e].c_edges = (uint16_t)(used - used0); // the edge that leads to the leaf (DCEdge::c_edges)
             E.e[my_e].c_off = (uint32_t)used0;
@@ -483,9 +491,9 @@ __device__ void dc_phase_apply(const TreeDev &d, const DCEdges &E, int g, int la
         nd->sq = __dsqrt_rn(1.0 + (double)all);
     }
     if (lane == 0) {
-        d.root_N[g] = root_n + 1;
-        if (pp) d.root_W[g] = root_w + ((pp == prev) ? v01 : vflip);
-        d.pend_leaf[g] = -1;
+        dc_ctl<SH>(d.root_N)[g] = root_n + 1;
+        if (pp) dc_ctl<SH>(d.root_W)[g] = root_w + ((pp == prev) ? v01 : vflip);
+        dc_ctl<SH>(d.pend_leaf)[g] = -1;
     }
 #ifdef BB_STAMPS
     (void)b0;
@@ -551,19 +559,20 @@ __device__ __forceinline__ DCEdge dc_edge_load(const DCEdge *p) {
 static_assert(offsetof(DCNode, sq) == 16 && offsetof(DCEdge, cP) == 16 && offsetof(DCEdge, act) == 24 &&
               offsetof(DCEdge, c_edges) == 26 && offsetof(DCEdge, c_off) == 28, "dc_head_load / dc_edge_load read these layouts");
 
+template <bool SH = false>
 __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int lane, float *lds) {
-    const int lid = d.game_lid[g], sims_left = d.sims_left[g];
-    int cur = d.root[g];
-    int nn = d.n_nodes[g];
+    const int lid = dc_ctl<SH>(d.game_lid)[g], sims_left = dc_ctl<SH>(d.sims_left)[g];
+    int cur = dc_ctl<SH>(d.root)[g];
+    int nn = dc_ctl<SH>(d.n_nodes)[g];
     const int nn0 = nn;
-    int used = E.used[g];
+    int used = dc_ctl<SH>(E.used)[g];
     // the counters the tail updates, requested with the first round of loads instead of after the descent
     int t_serial = 0;
     uint64_t t_evals = 0, t_c0 = 0, t_c1 = 0, t_c2 = 0, t_c3 = 0, t_c6 = 0;
-    uint64_t *ctr = d.ctr + (size_t)g * 8;
+    uint64_t *ctr = dc_ctl<SH>(d.ctr) + (size_t)g * 8;
     if (lane == 0) {
-        t_serial = d.sim_serial[g];
-        t_evals = d.evals[g];
+        t_serial = dc_ctl<SH>(d.sim_serial)[g];
+        t_evals = dc_ctl<SH>(d.evals)[g];
         t_c0 = ctr[0];
         t_c1 = ctr[1];
         t_c2 = ctr[2];
@@ -579,8 +588,8 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
 #define QS(acc) do {} while (0)
 #endif
     DCNode *pool = (DCNode *)d.nodes + (size_t)(g + d.pool_g0) * d.node_cap;
-    uint32_t *pn = d.path + (size_t)g * DragonChess::MAXPATH;
-    uint32_t *pe = E.path_edge + (size_t)g * DragonChess::MAXPATH;
+    uint32_t *pn = dc_ctl<SH>(d.path) + (size_t)g * DragonChess::MAXPATH;
+    uint32_t *pe = dc_ctl<SH>(E.path_edge) + (size_t)g * DragonChess::MAXPATH;
     int depth = 0, expand = 0, overflow = 0, term_leaf = 0;
     const bool inline_expand = d.priors_ones != 0;
     const bool fixed = d.kind == 1, rollout = d.evaluator == 2;
@@ -749,20 +758,20 @@ __device__ void dc_phase_select(const TreeDev &d, const DCEdges &E, int g, int l
         pn[lane] = my_pn;
         pe[lane] = my_pe;
     }
-    dc_lane_store((DCState *)d.leaf_state + g, st, lane);
+    dc_lane_store(dc_ctl<SH>((DCState *)d.leaf_state) + g, st, lane);
     if (lane == 0) {
-        d.leaf_game_id[g] = d.first_game_id + (uint32_t)lid;
-        d.leaf_serial[g] = cur;
-        d.pend_leaf[g] = cur;
-        d.pend_expand[g] = expand;
-        d.path_len[g] = depth;
-        d.sims_left[g] = sims_left - 1;
-        d.sim_serial[g] = t_serial + 1;
-        d.evals[g] = t_evals + 1;
+        dc_ctl<SH>(d.leaf_game_id)[g] = d.first_game_id + (uint32_t)lid;
+        dc_ctl<SH>(d.leaf_serial)[g] = cur;
+        dc_ctl<SH>(d.pend_leaf)[g] = cur;
+        dc_ctl<SH>(d.pend_expand)[g] = expand;
+        dc_ctl<SH>(d.path_len)[g] = depth;
+        dc_ctl<SH>(d.sims_left)[g] = sims_left - 1;
+        dc_ctl<SH>(d.sim_serial)[g] = t_serial + 1;
+        dc_ctl<SH>(d.evals)[g] = t_evals + 1;
         ctr[0] = t_c0 + 1;
         ctr[1] = t_c1 + (uint64_t)depth;
         if (nn != nn0) {
-            d.n_nodes[g] = nn;
+            dc_ctl<SH>(d.n_nodes)[g] = nn;
             ctr[2] = t_c2 + (uint64_t)(nn - nn0);
         }
         ctr[3] = t_c3 + (uint64_t)term_leaf;
