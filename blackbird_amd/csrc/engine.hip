@@ -532,7 +532,7 @@ extern "C" int bb_selfplay_mode(bb_engine *e) {
     // the persistent kernels carry a 16-filter network of at most MEGA_RMAX blocks in LDS; anything else runs as rounds
     const bool fits = !e->has_weights || (!e->general_net && e->net.R <= MEGA_RMAX && e->net.head_floats <= MEGA_HEAD_FLOATS);
     if (e->mega && fits) return 3;
-    if (e->dc_fused && (!e->has_weights || (!e->general_net && e->net.head_floats <= DC_HEAD_FLOATS))) return 5;
+    if (e->dc_fused && (!e->has_weights || (!e->general_net && e->net.head_floats <= DC_HEAD_FLOATS && e->net.R <= DC_RMAX))) return 5;
     return e->async_selfplay ? 1 : 0;
 }
 
@@ -1504,7 +1504,7 @@ extern "C" int bb_selfplay_step(bb_engine *e, int plies) {
     GAME_SWITCH(e->cfg.game, {
         if (e->async_selfplay) return selfplay_rounds_async<G>(e, plies * e->sims_now);
         if constexpr (G::GID == BB_GAME_DRAGONCHESS) {
-            if (e->dc_fused && e->has_weights && !e->general_net && e->net.head_floats <= DC_HEAD_FLOATS) {
+            if (e->dc_fused && e->has_weights && !e->general_net && e->net.head_floats <= DC_HEAD_FLOATS && e->net.R <= DC_RMAX) {
                 // at most 64 plies' worth of simulations per launch (a launch is plies x sims x ~45 us long; nothing inside can
                 // spin); the waves draw them from one pool (mega_dc.hip.h)
                 int cap = 64;

@@ -13,6 +13,8 @@
 #include "tree_dc.hip.h"
 
 #define DC_HEAD_FLOATS 12288 // packed head parameters (2 x 4032 policy kernel + 4032 bias + the small ones) kept in LDS: 48 KB
+#define DC_RMAX 8            // residual blocks whose bias / batch-norm constants (NetDev::epi, 48 floats per layer) fit the LDS copy
+#define DC_EPI_FLOATS (48 * (1 + 2 * DC_RMAX))
 
 // The three phases are separate functions on purpose: inlined into one loop body the compiler keeps every phase's
 // address arithmetic alive across the others (256 VGPRs + 402 spilled, slower than the launches it replaces).
@@ -128,6 +130,9 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
     static_assert(4 * WAVE_BYTES + DC_HEAD_FLOATS * 4 + 1024 <= 163840, "four waves' scratch and the head weights must fit the 160 KiB LDS");
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[4][WAVE_BYTES];
     __shared__ __attribute__((aligned(16))) float s_head[DC_HEAD_FLOATS];
+    // a layer's bias feeds its first MFMA: from L2 that is a full round trip at the top of every layer, and the wait for it also
+    // waits for the NEXT layer's weights, requested just before (vmcnt counts in order)
+    __shared__ __attribute__((aligned(16))) float s_epi[DC_EPI_FLOATS];
     __shared__ int myslot[4];
     __shared__ DCHeadLocal s_hl[4];
     // the phase functions take the three descriptor structs by reference: from LDS copies (made once) rather than from a
@@ -141,6 +146,7 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
     const int n_mine = d_arg.n_slots - g0 < 4 ? d_arg.n_slots - g0 : 4;
     shadow.load(d_arg, E_arg, g0, n_mine, blockDim.x);
     for (int i = threadIdx.x; i < nd_arg.head_floats; i += blockDim.x) s_head[i] = nd_arg.head[i]; // (host: head_floats <= DC_HEAD_FLOATS)
+    for (int i = threadIdx.x; i < 48 * (1 + 2 * nd_arg.R); i += blockDim.x) s_epi[i] = nd_arg.epi[i]; // (host: R <= DC_RMAX)
     if (threadIdx.x == 0) {
         TreeDev dl = d_arg;
         DCEdges El = E_arg;
@@ -149,6 +155,7 @@ __global__ void __launch_bounds__(256) k_dc_selfplay_fused(TreeDev d_arg, DCEdge
         s_E = El;
         s_nd = nd_arg;
         s_nd.head = s_head;
+        s_nd.epi = s_epi;
         s_x3 = x3_arg;
     }
     if (threadIdx.x < 4) {

@@ -221,8 +221,9 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
         for (int q = 0; q < 3; q++) w0a[q] = *(const bf16x8 *)(w0p + (q * 64 + lane) * 16);
         w0b = *(const bf16x8 *)(w0p + (3 * 64 + lane) * 16);
     }
-    const f32x4 bias0 = *(const f32x4 *)(nd.epi + 4 * g), scale0 = *(const f32x4 *)(nd.epi + 16 + 4 * g),
-                shift0 = *(const f32x4 *)(nd.epi + 32 + 4 * g);
+    const float *epi = PP ? as_lds(nd.epi) : nd.epi; // (the one-wave-per-game kernel keeps the constants in its LDS)
+    const f32x4 bias0 = *(const f32x4 *)(epi + 4 * g), scale0 = *(const f32x4 *)(epi + 16 + 4 * g),
+                shift0 = *(const f32x4 *)(epi + 32 + 4 * g);
     NSUB(5);
     if (zero_lds) {
         u32x4 z = {0u, 0u, 0u, 0u};
@@ -401,7 +402,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     if (L > 0 && !PP) request_layer(0);
     auto conv_layer = [&](const int l, auto skip_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr bool SKIP = decltype(skip_tag)::value, LAST = decltype(last_tag)::value;
-        const float *ep = nd.epi + (size_t)(1 + l) * 48;
+        const float *ep = epi + (size_t)(1 + l) * 48;
         const unsigned char *wp = x3.wt12 + (size_t)l * XG::LAYER12_B;
         {
             const f32x4 bias = *(const f32x4 *)(ep + 4 * g);
@@ -557,7 +558,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     };
     auto conv_layer_pp = [&](const int l, const WSet &ws, const unsigned char *src, unsigned char *dst, auto skip_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr bool SKIP = decltype(skip_tag)::value, LAST = decltype(last_tag)::value;
-        const float *ep = nd.epi + (size_t)(1 + l) * 48;
+        const float *ep = epi + (size_t)(1 + l) * 48;
         const f32x4 bias = *(const f32x4 *)(ep + 4 * g), scale = *(const f32x4 *)(ep + 16 + 4 * g), shift = *(const f32x4 *)(ep + 32 + 4 * g);
         // operand q of slice s: slices 0..3 = pixel planes 1, 2, 3; slice 4 (tap 8) = [x1;x2], [x3;x1], none
         auto xaddr = [&](int s, int t, int q) __attribute__((always_inline)) {
