@@ -171,6 +171,13 @@ __device__ __forceinline__ void x3_split4(const f32x4 y, u32x2 &p1, u32x2 &p2, u
 // tile t's 27 MFMAs execute (a bf16 MFMA leaves 8 of its 16 cycles to the wave's vector instructions).
 // HEADS_OUT (persistent kernel): the wave stops after the three pooled head activations (R, R0, R1) and hands them to the
 // caller's `pooled_out` -- the value / policy tails (head_one) then run on the tree wave that picks the result up.
+// 16 bytes of packed weights from device memory through the global address space.  In a kernel that reaches its weights
+// through a descriptor copied to LDS (mega_dc.hip.h) the pointers are generic, the loads flat: a flat load counts on lgkmcnt
+// too and may return out of order with LDS reads, so with one in flight every wait for an LDS operand becomes a wait for
+// everything -- a layer's first MFMA then waits for the NEXT layer's weights, requested a moment earlier.
+__device__ __forceinline__ bf16x8 x3_ldg(const unsigned char *p) {
+    return *(const __attribute__((address_space(1))) bf16x8 *)(const void *)p;
+}
 #ifdef BB_STAMPS_NET_SUB
 #define NSUB(i) NSTAMP(i) // prologue split (diagnostic): 5 = loads issued + zero fill, 6 = state to LDS, 7 = planes; 0 = the rest
 #else
@@ -215,7 +222,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     bf16x8 w0b;                   // narrow input: tap 8's three weight planes side by side in one K = 32 operand
     if constexpr (WIDE_IN) {
 #pragma unroll
-        for (int i = 0; i < 27; i++) w0a[i] = *(const bf16x8 *)(w0p + (i * 64 + lane) * 16);
+        for (int i = 0; i < 27; i++) w0a[i] = WLDS ? *(const bf16x8 *)(w0p + (i * 64 + lane) * 16) : x3_ldg(w0p + (i * 64 + lane) * 16);
     } else {
 #pragma unroll
         for (int q = 0; q < 3; q++) w0a[q] = *(const bf16x8 *)(w0p + (q * 64 + lane) * 16);
@@ -544,17 +551,16 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     // alternates them, so no register copies are needed.
     struct WSet { bf16x8 w1[5], w2[5], w3[5]; };
     auto request_set = [&](WSet &ws, int l) __attribute__((always_inline)) {
-        const unsigned char *g12 = as_global(x3.wt12) + (size_t)l * XG::LAYER12_B, *g3 = as_global(x3.wt3) + (size_t)l * XG::LAYER3_B,
-                            *g8 = as_global(x3.wt8) + (size_t)l * 3 * 1024;
+        const unsigned char *g12 = x3.wt12 + (size_t)l * XG::LAYER12_B, *g3 = x3.wt3 + (size_t)l * XG::LAYER3_B, *g8 = x3.wt8 + (size_t)l * 3 * 1024;
 #pragma unroll
         for (int sl = 0; sl < 4; sl++) {
-            ws.w1[sl] = *(const bf16x8 *)(g12 + ((sl * 2 + 0) * 64 + lane) * 16);
-            ws.w2[sl] = *(const bf16x8 *)(g12 + ((sl * 2 + 1) * 64 + lane) * 16);
-            ws.w3[sl] = *(const bf16x8 *)(g3 + (sl * 64 + lane) * 16);
+            ws.w1[sl] = x3_ldg(g12 + ((sl * 2 + 0) * 64 + lane) * 16);
+            ws.w2[sl] = x3_ldg(g12 + ((sl * 2 + 1) * 64 + lane) * 16);
+            ws.w3[sl] = x3_ldg(g3 + (sl * 64 + lane) * 16);
         }
-        ws.w1[4] = *(const bf16x8 *)(g8 + (0 * 64 + lane) * 16); // [w1|w1]
-        ws.w2[4] = *(const bf16x8 *)(g8 + (1 * 64 + lane) * 16); // [w2|w2]
-        ws.w3[4] = *(const bf16x8 *)(g8 + (2 * 64 + lane) * 16); // [w1|w3]
+        ws.w1[4] = x3_ldg(g8 + (0 * 64 + lane) * 16); // [w1|w1]
+        ws.w2[4] = x3_ldg(g8 + (1 * 64 + lane) * 16); // [w2|w2]
+        ws.w3[4] = x3_ldg(g8 + (2 * 64 + lane) * 16); // [w1|w3]
     };
     auto conv_layer_pp = [&](const int l, const WSet &ws, const unsigned char *src, unsigned char *dst, auto skip_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr bool SKIP = decltype(skip_tag)::value, LAST = decltype(last_tag)::value;
@@ -673,8 +679,9 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     float x = 0.f, x0 = 0.f, x1 = 0.f;
     {
         const unsigned char *whp = x3.wh;
-        const bf16x8 h1 = *(const bf16x8 *)(whp + (0 * 64 + lane) * 16), h2 = *(const bf16x8 *)(whp + (1 * 64 + lane) * 16),
-                     h3 = *(const bf16x8 *)(whp + (2 * 64 + lane) * 16);
+        const bf16x8 h1 = PP ? x3_ldg(whp + (0 * 64 + lane) * 16) : *(const bf16x8 *)(whp + (0 * 64 + lane) * 16),
+                     h2 = PP ? x3_ldg(whp + (1 * 64 + lane) * 16) : *(const bf16x8 *)(whp + (1 * 64 + lane) * 16),
+                     h3 = PP ? x3_ldg(whp + (2 * 64 + lane) * 16) : *(const bf16x8 *)(whp + (2 * 64 + lane) * 16);
         const f32x4 hb = g == 0 ? f32x4{v3[0], p6[0], p6[1], 0.f} : f32x4{0.f, 0.f, 0.f, 0.f}; // the convolutions' biases
         bf16x8 y1[NT], y3[NT];
 #pragma unroll
