@@ -674,10 +674,13 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     // rows 0..2 of a 16-filter operand, the three plane-concatenated products of tap 8 at the pixel itself -- then BN + ReLU and
     // the spatial sums: lane (g = 0, nn) holds the three head activations of column nn of every tile.  (Round 2 formed them
     // on the vector ALUs from a float32 copy of the last layer: 48 fmas and four 16-byte reads per pixel, 2.0 k cycles.)
-    const float *hp = nd.head;
-    const float *v3 = hp + nd.off_v3, *p6 = hp + nd.off_p6;
+    const float *hp = PP ? as_lds(nd.head) : nd.head; // (the one-wave-per-game kernel keeps the head parameters in its LDS)
     float x = 0.f, x0 = 0.f, x1 = 0.f;
     {
+        // the nine constants of the two head convolutions, read once and by every lane: inside the `g == 0` branch below each
+        // tile re-read them and waited for them on the spot
+        const float *v3p = hp + nd.off_v3, *p6p = hp + nd.off_p6;
+        const float v3[3] = {v3p[0], v3p[1], v3p[2]}, p6[6] = {p6p[0], p6p[1], p6p[2], p6p[3], p6p[4], p6p[5]};
         const unsigned char *whp = x3.wh;
         const bf16x8 h1 = PP ? x3_ldg(whp + (0 * 64 + lane) * 16) : *(const bf16x8 *)(whp + (0 * 64 + lane) * 16),
                      h2 = PP ? x3_ldg(whp + (1 * 64 + lane) * 16) : *(const bf16x8 *)(whp + (1 * 64 + lane) * 16),
