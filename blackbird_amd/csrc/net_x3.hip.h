@@ -598,13 +598,68 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
                 }
             }
         };
+        // Tile t - 1's epilogue, cut into pieces of one or two vector instructions and placed by hand: piece m runs right after
+        // MFMA m of tile t (a bf16 MFMA leaves 8 of its 16 cycles to the wave's vector instructions), each MFMA + piece pair fenced
+        // so that the order stands.  (Left to the scheduler -- sched_group_barrier patterns -- the pieces ended up in two
+        // clumps, the larger one of ~25 instructions BETWEEN two tiles with the matrix pipe idle: ~150 cycles per tile.)
+        float ev[4];
+        unsigned ea[2], eb[2], ec[2];
+        float er1[4], er2[4];
+        auto ep_piece = [&](int t1, int m) __attribute__((always_inline)) {
+            switch (m) {
+            case 0: case 1: case 2: case 3: {
+                float v = __builtin_fmaf(acc[t1][m], scale[m], shift[m]);
+                if constexpr (SKIP) v = v + sk[t1][m];
+                ev[m] = v;
+                break;
+            }
+            case 4: ev[0] = fmaxf(ev[0], 0.f); ev[1] = fmaxf(ev[1], 0.f); break;
+            case 5: ev[2] = fmaxf(ev[2], 0.f); ev[3] = fmaxf(ev[3], 0.f); if constexpr (SKIP) sk[t1] = f32x4{ev[0], ev[1], ev[2], ev[3]}; break;
+            case 6: ea[0] = cvt_pk_bf16(ev[0], ev[1]); break;
+            case 7: ea[1] = cvt_pk_bf16(ev[2], ev[3]); break;
+            case 8: er1[0] = ev[0] - __uint_as_float(ea[0] << 16); break;
+            case 9: er1[1] = ev[1] - __uint_as_float(ea[0] & 0xffff0000u); break;
+            case 10: er1[2] = ev[2] - __uint_as_float(ea[1] << 16); break;
+            case 11: er1[3] = ev[3] - __uint_as_float(ea[1] & 0xffff0000u); break;
+            case 12: eb[0] = cvt_pk_bf16(er1[0], er1[1]); break;
+            case 13: eb[1] = cvt_pk_bf16(er1[2], er1[3]); break;
+            case 14: er2[0] = er1[0] - __uint_as_float(eb[0] << 16); break;
+            case 15: er2[1] = er1[1] - __uint_as_float(eb[0] & 0xffff0000u); break;
+            case 16: er2[2] = er1[2] - __uint_as_float(eb[1] << 16); break;
+            case 17: er2[3] = er1[3] - __uint_as_float(eb[1] & 0xffff0000u); break;
+            case 18: ec[0] = cvt_pk_bf16(er2[0], er2[1]); break;
+            case 19: ec[1] = cvt_pk_bf16(er2[2], er2[3]); break;
+            case 20:
+                if (wv[t1]) {
+                    *(u32x2 *)(dst + aO(t1)) = u32x2{ea[0], ea[1]};
+                    *(u32x2 *)(dst + aO(t1) + 32) = u32x2{eb[0], eb[1]};
+                    *(u32x2 *)(dst + aO(t1) + 64) = u32x2{ec[0], ec[1]};
+                }
+                break;
+            default: break;
+            }
+            // (pin the piece here: pure arithmetic is otherwise sunk to its first user, the stores of piece 20)
+            if (m < 4) asm volatile("" : "+v"(ev[m]));
+            else if (m == 4) asm volatile("" : "+v"(ev[0]), "+v"(ev[1]));
+            else if (m == 5) asm volatile("" : "+v"(ev[2]), "+v"(ev[3]));
+            else if (m == 6 || m == 7) asm volatile("" : "+v"(ea[m - 6]));
+            else if (m >= 8 && m < 12) asm volatile("" : "+v"(er1[m - 8]));
+            else if (m == 12 || m == 13) asm volatile("" : "+v"(eb[m - 12]));
+            else if (m >= 14 && m < 18) asm volatile("" : "+v"(er2[m - 14]));
+            else if (m == 18 || m == 19) asm volatile("" : "+v"(ec[m - 18]));
+        };
+        (void)LAST;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             acc[t] = bias;
-            // One scheduling region per tile: its 27 MFMAs, the operand reads two slices ahead and tile t - 1's epilogue (~60 vector
-            // instructions, three writes), dealt out by the group barriers below: per slice its reads, then per MFMA up to two
-            // vector instructions, which fit in the 8 cycles of its 16 that a bf16 MFMA leaves to the wave.
             __builtin_amdgcn_sched_barrier(0);
+            int m = 0;
+            auto MF = [&](const bf16x8 &w, const bf16x8 &x) __attribute__((always_inline)) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc[t], 0, 0, 0);
+                if (t > 0) ep_piece(t - 1, m);
+                m++;
+                __builtin_amdgcn_sched_barrier(0);
+            };
 #pragma unroll
             for (int s = 0; s < 5; s++) {
                 const int sn = (s + 2) % 5, tn = s + 2 < 5 ? t : t + 1;
@@ -613,17 +668,18 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
                     for (int q = 0; q < 3; q++)
                         if (q < nops(sn)) xnn[q] = *(const bf16x8 *)(src + xaddr(sn, tn, q));
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 if (s < 4) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w3[s], xc[0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w2[s], xc[0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[s], xc[0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w2[s], xc[1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[s], xc[1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[s], xc[2], acc[t], 0, 0, 0);
+                    MF(ws.w3[s], xc[0]);
+                    MF(ws.w2[s], xc[0]);
+                    MF(ws.w1[s], xc[0]);
+                    MF(ws.w2[s], xc[1]);
+                    MF(ws.w1[s], xc[1]);
+                    MF(ws.w1[s], xc[2]);
                 } else {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w3[4], xc[1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w2[4], xc[0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws.w1[4], xc[0], acc[t], 0, 0, 0);
+                    MF(ws.w3[4], xc[1]);
+                    MF(ws.w2[4], xc[0]);
+                    MF(ws.w1[4], xc[0]);
                 }
 #pragma unroll
                 for (int q = 0; q < 3; q++) {
@@ -631,18 +687,8 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
                     xn[q] = xnn[q];
                 }
             }
-            if (t > 0) epilogue(t - 1);
-#define X3_PP_GROUP(NREAD, NMFMA)                                                                      \
-    __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0); /* DS read */                              \
-    _Pragma("unroll") for (int k = 0; k < NMFMA; k++) {                                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* MFMA */                                 \
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); /* VALU */                                 \
-    }
-            X3_PP_GROUP(3, 6) X3_PP_GROUP(3, 6) X3_PP_GROUP(2, 6) X3_PP_GROUP(3, 6) X3_PP_GROUP(3, 3) // (reads are two slices ahead: tap 8 has two)
-#undef X3_PP_GROUP
-            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0); // DS write
-            __builtin_amdgcn_sched_barrier(0);
         }
+        (void)epilogue;
         epilogue(NT - 1);
         wave_lds_handover();
     };
