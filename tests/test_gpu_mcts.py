@@ -265,3 +265,61 @@ def test_dc_selfplay_one_wave_per_game(orc):
                 pi[r["action"][k][:nch]] = r["visits"][k][:nch] / float(r["total"][k])
             assert np.array_equal(pi, o["pi"][k]), (gidx, k)
     ev.close()
+
+
+@pytest.mark.parametrize("game,og,n_slots,n_games,sims,cap", [
+    (_lib.GAME_CONNECT4, 0, 19, 24, 40, 43),      # persistent work-queue kernel (mode 3)
+    (_lib.GAME_DRAGONCHESS, 2, 5, 6, 16, 14),     # one wave per game (mode 5)
+])
+def test_exact_ties_follow_the_float64_first_maximum(orc, game, og, n_slots, n_games, sims, cap):
+    """The float32 pre-filter of the PUCT argmax (tree.hip.h grp_argmax_puct, tree_dc.hip.h select) must hand every tie to
+    the float64 path.  An all-zero network makes ties the rule: every prior is 1 / legal moves, every value 0.5, so
+    unvisited children tie EXACTLY and np.argmax's first-maximum decides -- the engine's visit counts, moves and winners
+    must be the oracle's, example by example (noise off; the oracle's callback gets the engine's own network outputs)."""
+    from blackbird_amd import weights as W
+    gi = _lib.game_info(game)
+    w = W.init_weights(gi.C, 16, 2, 16, gi.A, seed=3)
+    # (batch-norm variances stay at one; kernels, biases, gammas, betas and means are zero)
+    wz = {k: (np.ones_like(v) if "variance" in k else np.zeros_like(v)) for k, v in w.items()}
+    flat = W.flatten(wz)
+    eng = _lib.Engine(game, n_slots=n_slots, sims_per_move=sims, evaluator=_lib.EVAL_NET, seed=11, max_games=n_games,
+                      max_plies=cap, noise_on=False)
+    eng.load_weights(flat)
+    assert eng.selfplay_mode() in (3, 5)
+    eng.selfplay_begin(n_games, 1.0)
+    guard = 0
+    while not eng.selfplay_done()[0]:
+        eng.selfplay_step(3)
+        guard += 1
+        assert guard < 200 and eng.counters()["overflow"] == 0
+    rec, offs, win = eng.fetch_examples()
+    eng.close()
+    ev = _lib.Engine(game, n_slots=4, sims_per_move=2, evaluator=_lib.EVAL_NET)
+    ev.load_weights(flat)
+    st0 = _lib.game_initial(game)
+    v0, _l0, p0 = ev.net_eval(states=st0)
+    assert float(v0[0]) == 0.0 and np.ptp(p0[0]) == 0.0  # the ties are real: uniform policy, zero value
+
+    def cb(_ctx, stp, vp, pp):
+        v, _l, p = ev.net_eval(planes=orc.encode(og, stp.contents))
+        vp[0] = float(v[0])
+        if pp:
+            for i in range(gi.A):
+                pp[i] = float(p[0, i])
+
+    cfg = orc.make_cfg(og, evaluator=orc.EVAL_CALLBACK, seed=11, cb=orc.EVAL_CB(cb))
+    for gidx in range(n_games):
+        o = orc.selfplay_game(cfg, gidx, 1.0, sims, cap - 1 if gi.dense else cap)
+        r = rec[offs[gidx]:offs[gidx + 1]]
+        assert len(r) == o["n"] and win[gidx] == o["winner"], gidx
+        for k in range(len(r)):
+            pi = np.zeros(gi.A)
+            if r["total"][k] > 0:
+                if gi.dense:
+                    pi[:] = r["visits"][k][:gi.A] / float(r["total"][k])
+                else:
+                    nch = int(r["n_children"][k])
+                    pi[r["action"][k][:nch]] = r["visits"][k][:nch] / float(r["total"][k])
+            assert np.array_equal(pi, o["pi"][k]), (gidx, k)
+        assert np.array_equal(r["player"], o["player"]) and np.array_equal(r["z"].astype(np.float32), o["z"])
+    ev.close()
