@@ -240,12 +240,20 @@ __device__ __forceinline__ int grp_argmax_puct(float qf, double cPi, double sq, 
     mf = __builtin_fmaxf(mf, __int_as_float(dpp_step_i<1>(__float_as_int(mf))));
     mf = __builtin_fmaxf(mf, __int_as_float(dpp_step_i<2>(__float_as_int(mf))));
     if (S == 16) mf = __builtin_fmaxf(mf, __int_as_float(dpp_step_i<3>(__float_as_int(mf))));
-    const unsigned long long cand = __ballot(uf >= mf - mf * 0x1p-18f && uf >= 0.0f);
+    const bool mine = uf >= mf - mf * 0x1p-18f && uf >= 0.0f;
+    const unsigned long long cand = __ballot(mine);
     const int l64 = (int)__lane_id();
     const unsigned grp = (unsigned)(cand >> (l64 & ~(S - 1))) & ((1u << S) - 1u);
     if (__ballot((grp & (grp - 1u)) != 0u || grp == 0u) == 0ull) { // one candidate in every group of the wave
         const int win = __ffs(grp) - 1;
-        payload = __shfl(payload, win, S);
+        // the winner's payload to every lane of its group: an OR butterfly over the group's DPP steps (one lane contributes)
+        // instead of a cross-lane read through LDS (ds_bpermute: a round trip on the critical path of every tree level)
+        int p = mine ? payload : 0;
+        p |= dpp_step_i<0>(p);
+        p |= dpp_step_i<1>(p);
+        p |= dpp_step_i<2>(p);
+        if (S == 16) p |= dpp_step_i<3>(p);
+        payload = p;
         return win;
     }
 #endif
