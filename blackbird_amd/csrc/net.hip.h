@@ -203,11 +203,12 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
     const float *d1k = hp + nd.off_d1k, *d1b = hp + nd.off_d1b, *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
     const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
     auto lane_f = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
-    // value head: dense_1 on the pooled activation (unit d on lane d), ReLU, dense_2 as an ordered fma chain, tanh
+    // value head: dense_1 on the pooled activation (unit d on lane d), ReLU, dense_2 = the products folded by the fixed pairwise
+    // tree of pooled_sum (TensorFlow leaves the order of a matmul's sum open; the oracle restates this one), + bias, tanh.
+    // (Until round 3 an fma chain in unit order: D dependent steps of two v_readlane each on the tail every game waits for.)
     const float sdv = lane < D ? fmaxf(__builtin_fmaf(R, d1k[lane], (float)HW * d1b[lane]), 0.f) : 0.f;
-    const float d2kv = lane < D ? d2k[lane] : 0.f; // (one load: a d2k[dd] per step of the chain below is a dependent LDS / L2 round trip each, ~2 k cycles at D = 16)
-    float e = d2b[0];
-    for (int dd = 0; dd < D; dd++) e = __builtin_fmaf(lane_f(sdv, dd), lane_f(d2kv, dd), e);
+    const float d2kv = lane < D ? d2k[lane] : 0.f;
+    const float e = wave_sum_f32(sdv * d2kv) + d2b[0];
     // tanh on the hardware exponential: 1 - 2 / (exp(2e) + 1) (v_exp_f32, v_rcp_f32: absolute error ~1e-7, the library tanhf is
     // ~60 instructions on the network wave's critical tail); saturates to +-1 through exp's overflow / underflow
     const float value = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(e * 2.88539008177792681472f) + 1.0f);
@@ -274,17 +275,13 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
         }
     } else {
         static_assert(A > 64 || 2 * A <= 64, "the prior-noise draws use two lanes per action");
-        // policy: action a on lane a.  softmax sums run in ascending action order over readlane broadcasts (the oracle's
-        // sequential `tot += p[a]`), so they do not depend on the lane layout.
+        // policy: action a on lane a (lanes >= A hold -inf / 0).  The softmax maximum and sums are the wave reductions of
+        // pooled_sum -- the fixed pairwise tree the oracle restates (tree_sum64) -- not chains of A readlane steps.
         const bool act = lane < A;
         const float l = act ? wide_logit<HW>(R0, R1, pdk[act ? lane : 0], pdk[A + (act ? lane : 0)], pdb[act ? lane : 0]) : -INFINITY;
-        float m = -INFINITY;
-#pragma unroll
-        for (int a = 0; a < A; a++) m = fmaxf(m, lane_f(l, a));
+        const float m = wave_max_f32(l);
         float pr = act ? wide_expterm(l, m) : 0.f; // exp(l - m) on v_exp_f32, as the wide head does
-        float tot = 0.f;
-#pragma unroll
-        for (int a = 0; a < A; a++) tot += lane_f(pr, a);
+        const float tot = wave_sum_f32(pr);
         pr = pr / tot;
         if (noise) { // policy = (1-eps)*softmax + eps*Beta(alpha,1-alpha); policy /= sum(policy)   (NetworkFactory.py:176-182)
             // two lanes per action: lane pair (2a, 2a+1) tries Philox pairs k and k+1 side by side
@@ -305,9 +302,7 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
             float nz = __shfl(r, 2 * (act ? lane : 0), 64); // action a's draw sits on lane 2a
             if (noise_ready) nz = act ? noise_ready[lane] : 0.f; // the same draws (bb_beta_noise: same trials in the same order), made ahead
             pr = (1.0f - nd.eps) * pr + nd.eps * (act ? nz : 0.f);
-            float t2 = 0.f;
-#pragma unroll
-            for (int a = 0; a < A; a++) t2 += lane_f(pr, a);
+            const float t2 = wave_sum_f32(pr);
             pr = pr / t2;
         }
         if (live && act && logits_out) logits_out[(size_t)pos * A + lane] = l;
@@ -328,40 +323,49 @@ __device__ __forceinline__ float head_tree(const NetDev &nd, const float *hp, fl
     const int D = nd.D;
     const float *d1k = hp + nd.off_d1k, *d1b = hp + nd.off_d1b, *d2k = hp + nd.off_d2k, *d2b = hp + nd.off_d2b;
     const float *pdk = hp + nd.off_pdk, *pdb = hp + nd.off_pdb;
-    float e = d2b[0];
-    { // (four units per round trip: the three parameter rows are 16-byte aligned in the packed head -- engine.hip `push`)
-        int dd = 0;
-        for (; dd + 4 <= D; dd += 4) {
-            const f32x4 k1 = *(const f32x4 *)(d1k + dd), b1 = *(const f32x4 *)(d1b + dd), k2 = *(const f32x4 *)(d2k + dd);
+    // (the orders of head_one: products / terms in slots 0 .. 63 of a vector -- the rest zero -- folded by strides 1, 2, ..., 32,
+    // i.e. the tree of wave_sum_f32; zeros add exactly, so only the occupied part of the tree is walked)
+    auto tree16 = [](float *t) __attribute__((always_inline)) { // 16 slots -> t[0]
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float sdv = fmaxf(__builtin_fmaf(R, k1[r], (float)HW * b1[r]), 0.f);
-                e = __builtin_fmaf(sdv, k2[r], e);
+        for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2 * o) t[i] = t[i] + t[i + o];
+        return t[0];
+    };
+    float e = 0.f;
+    { // (four units per round trip: the three parameter rows are 16-byte aligned in the packed head -- engine.hip `push`)
+        float blk[4] = {0.f, 0.f, 0.f, 0.f}; // sums of slots 0-15, 16-31, 32-47, 48-63
+        for (int b16 = 0; b16 < 4 && b16 * 16 < D; b16++) {
+            float t[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) t[r] = 0.f;
+            for (int dd = b16 * 16; dd < D && dd < b16 * 16 + 16; dd++) {
+                const float sdv = fmaxf(__builtin_fmaf(R, d1k[dd], (float)HW * d1b[dd]), 0.f);
+                t[dd & 15] = sdv * d2k[dd];
             }
+            blk[b16] = tree16(t);
         }
-        for (; dd < D; dd++) {
-            const float sdv = fmaxf(__builtin_fmaf(R, d1k[dd], (float)HW * d1b[dd]), 0.f);
-            e = __builtin_fmaf(sdv, d2k[dd], e);
-        }
+        e = ((blk[0] + blk[1]) + (blk[2] + blk[3])) + d2b[0];
     }
     const float value = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(e * 2.88539008177792681472f) + 1.0f);
     const bool act = lane < A;
     const int la = act ? lane : 0;
     const float l = act ? wide_logit<HW>(R0, R1, pdk[la], pdk[A + la], pdb[la]) : -INFINITY;
+    static_assert(A <= 16, "head_tree: the actions of a dense game fit one 16-slot block of the tree");
     float m = -INFINITY;
 #pragma unroll
     for (int a = 0; a < A; a++) m = fmaxf(m, __shfl(l, base + a, 64));
     float pr = act ? wide_expterm(l, m) : 0.f;
-    float tot = 0.f;
+    auto gsum = [&](float v) __attribute__((always_inline)) {
+        float t[16];
 #pragma unroll
-    for (int a = 0; a < A; a++) tot += __shfl(pr, base + a, 64);
-    pr = pr / tot;
+        for (int a = 0; a < 16; a++) t[a] = a < A ? __shfl(v, base + a, 64) : 0.f;
+        return tree16(t);
+    };
+    pr = pr / gsum(pr);
     if (noise) {
         pr = (1.0f - nd.eps) * pr + nd.eps * (act ? nz : 0.f);
-        float t2 = 0.f;
-#pragma unroll
-        for (int a = 0; a < A; a++) t2 += __shfl(pr, base + a, 64);
-        pr = pr / t2;
+        pr = pr / gsum(pr);
     }
     *prior_out = act ? pr : 0.f;
     return value;

@@ -145,13 +145,16 @@ static void net_forward_impl(const orc_net *w, const int8_t *boards, int n, floa
                 rv[p] = v > 0.f ? v : 0.f;
             }
             float e = w->v_d2_b[0];
-            if (pooled) { /* dense_1 after the pool: relu(k[d] * sum_p rv[p] + HW * b[d]) */
+            if (pooled) { /* dense_1 after the pool: relu(k[d] * sum_p rv[p] + HW * b[d]); dense_2: the products folded by
+                           * the same fixed tree (TensorFlow leaves the order of a matmul's sum open), then the bias */
                 float Rv = tree_sum64(rv, HW, 1);
-                for (int d = 0; d < D; d++) {
+                float prod[64];
+                for (int d = 0; d < D && d < 64; d++) {
                     float s = fmaf(Rv, w->v_d1_k[d], (float)HW * w->v_d1_b[d]);
                     s = s > 0.f ? s : 0.f;
-                    e = fmaf(s, w->v_d2_k[d], e);
+                    prod[d] = s * w->v_d2_k[d];
                 }
+                e = tree_sum64(prod, D < 64 ? D : 64, 1) + w->v_d2_b[0];
             } else {
                 for (int d = 0; d < D; d++) {
                     float s = 0.f; /* dense_1 per pixel (:125-127) then reduce_sum over H,W (:129-131) */
@@ -196,6 +199,7 @@ static void net_forward_impl(const orc_net *w, const int8_t *boards, int n, floa
                 lg[a] = expf(lg[a] - m);
                 tot += lg[a];
             }
+            if (pooled && A <= 64) tot = tree_sum64(lg, A, 1); /* the kernels' softmax sum: the same fixed tree (narrow heads) */
             if (policy)
                 for (int a = 0; a < A; a++) policy[(size_t)b * A + a] = lg[a] / tot;
         }
