@@ -773,8 +773,8 @@ static int launch_gnet(bb_engine *e, int n_max, const int *n_ptr, const int *slo
 //       groups 2, 3 plane 3, channels 8 (g & 1) .. + 7
 // wt8:  per layer [3][lane][8]: tap 8's three A operands [w1|w1], [w2|w2], [w1|w3] as 64-lane images (PP form)
 // (tap 8 = three K = 32 products on plane-concatenated operands: [w1|w1].[x1;x2] + [w2|w2].[x1;x2] + [w1|w3].[x3;x1], net_x3.hip.h)
-// wh:   [3][lane][8]: the head convolutions as a 16-filter K = 16 layer -- filter 0 = value conv, 1 and 2 = policy conv, the rest
-//       zero -- in the three operands of tap 8
+// wh:   [3][lane][8]: the head convolutions as a 16-filter K = 16 layer -- filter 0 = value conv, 4 and 8 = policy conv, the rest
+//       zero (so that lane groups 0, 1, 2 of the result each hold ONE head's activation) -- in the three operands of tap 8
 static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vector<uint16_t> &wt12, std::vector<uint16_t> &wt3,
                     std::vector<uint16_t> &wt8, std::vector<uint16_t> &wh) {
     const int F = 16, C = w->C, R = w->R;
@@ -811,9 +811,10 @@ static void pack_x3(const bb_net_weights *w, std::vector<uint16_t> &w0, std::vec
     wh.assign((size_t)3 * 64 * 8, 0);
     for (int lane = 0; lane < 64; lane++) {
         const int f = lane & 15, g = lane >> 4;
-        for (int i = 0; i < 8 && f < 3; i++) {
+        const int head = f == 0 ? 0 : f == 4 ? 1 : f == 8 ? 2 : -1; // filter rows 0, 4, 8: the first result register of lane groups 0, 1, 2
+        for (int i = 0; i < 8 && head >= 0; i++) {
             const int ch = 8 * (g & 1) + i;
-            bf16_split3(f == 0 ? w->v_conv_k[ch] : w->p_conv_k[(size_t)ch * 2 + (f - 1)], h);
+            bf16_split3(head == 0 ? w->v_conv_k[ch] : w->p_conv_k[(size_t)ch * 2 + (head - 1)], h);
             wh[((size_t)0 * 64 + lane) * 8 + i] = h[0];
             wh[((size_t)1 * 64 + lane) * 8 + i] = h[1];
             wh[((size_t)2 * 64 + lane) * 8 + i] = g < 2 ? h[0] : h[2];

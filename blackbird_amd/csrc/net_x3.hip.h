@@ -721,46 +721,57 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     // the spatial sums: lane (g = 0, nn) holds the three head activations of column nn of every tile.  (Round 2 formed them
     // on the vector ALUs from a float32 copy of the last layer: 48 fmas and four 16-byte reads per pixel, 2.0 k cycles.)
     const float *hp = PP ? as_lds(nd.head) : nd.head; // (the one-wave-per-game kernel keeps the head parameters in its LDS)
-    float x = 0.f, x0 = 0.f, x1 = 0.f;
+    // Filter rows 0, 4 and 8 of the operand are the value conv and the two policy convs (engine.hip pack_x3), so lane group g
+    // (< 3) finds the activation of head g in the FIRST result register: one accumulator per lane, and the three spatial sums
+    // are ONE row-wise reduction -- rows 0, 1, 2 of the wave -- instead of three wave reductions.  (Same bits as three
+    // pooled_sum calls on a value that is zero outside row 0: the other rows only ever added exact zeros.)
+    float R, R0, R1;
     {
-        // the nine constants of the two head convolutions, read once and by every lane: inside the `g == 0` branch below each
-        // tile re-read them and waited for them on the spot
         const float *v3p = hp + nd.off_v3, *p6p = hp + nd.off_p6;
-        const float v3[3] = {v3p[0], v3p[1], v3p[2]}, p6[6] = {p6p[0], p6p[1], p6p[2], p6p[3], p6p[4], p6p[5]};
+        // this lane group's constants, read once and by every lane: conv bias, batch-norm scale and shift
+        // (by address, not by a chain of selects: v3 = {bias, scale, shift}, p6 = {bias0, bias1, scale0, scale1, shift0, shift1};
+        // the fourth lane group reads group 2's and is masked out of the sum)
+        const float *cp = g == 0 ? v3p : p6p + (g == 1 ? 0 : 1);
+        const int cs = g == 0 ? 1 : 2;
+        const float hbias = cp[0], hscale = cp[cs], hshift = cp[2 * cs];
         const unsigned char *whp = x3.wh;
         const bf16x8 h1 = PP ? x3_ldg(whp + (0 * 64 + lane) * 16) : *(const bf16x8 *)(whp + (0 * 64 + lane) * 16),
                      h2 = PP ? x3_ldg(whp + (1 * 64 + lane) * 16) : *(const bf16x8 *)(whp + (1 * 64 + lane) * 16),
                      h3 = PP ? x3_ldg(whp + (2 * 64 + lane) * 16) : *(const bf16x8 *)(whp + (2 * 64 + lane) * 16);
-        const f32x4 hb = g == 0 ? f32x4{v3[0], p6[0], p6[1], 0.f} : f32x4{0.f, 0.f, 0.f, 0.f}; // the convolutions' biases
+        const f32x4 hb = {hbias, 0.f, 0.f, 0.f};
         bf16x8 y1[NT], y3[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             y1[t] = *(const bf16x8 *)(X + aH1(t));
             y3[t] = *(const bf16x8 *)(X + aH3(t));
         }
+        float xs = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             f32x4 a = hb;
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h3, y3[t], a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h2, y1[t], a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, y1[t], a, 0, 0, 0);
-            if (g == 0 && wv[t]) { // (halo columns and the other lane groups contribute exact zeros to the sums below)
-                x += fmaxf(__builtin_fmaf(a[0], v3[1], v3[2]), 0.f);
-                x0 += fmaxf(__builtin_fmaf(a[1], p6[2], p6[4]), 0.f);
-                x1 += fmaxf(__builtin_fmaf(a[2], p6[3], p6[5]), 0.f);
-            }
+            const float v = fmaxf(__builtin_fmaf(a[0], hscale, hshift), 0.f);
+            xs += (g < 3 && wv[t]) ? v : 0.f; // (halo columns and the fourth lane group contribute exact zeros)
         }
+        xs += dpp_f32(xs, 0);
+        xs += dpp_f32(xs, 1);
+        xs += dpp_f32(xs, 2);
+        xs += dpp_f32(xs, 3);
+        R = lane_f32(xs, 0);
+        R0 = lane_f32(xs, 16);
+        R1 = lane_f32(xs, 32);
     }
     NSTAMP(3);
     if constexpr (HEADS_OUT) {
-        const float R = pooled_sum(x), R0 = pooled_sum(x0), R1 = pooled_sum(x1);
         if (lane == 0) {
             pooled_out[0] = R;
             pooled_out[1] = R0;
             pooled_out[2] = R1;
         }
     } else {
-    head_one<G>(nd, pooled_sum(x), pooled_sum(x0), pooled_sum(x1), live ? OI(pos0) : 0, live, game_id, serial, noise, value_out,
+    head_one<G>(nd, R, R0, R1, live ? OI(pos0) : 0, live, game_id, serial, noise, value_out,
                 logits_out, policy_out, pstride, compact, noise_ready);
     }
     NSTAMP(4);
