@@ -128,6 +128,22 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     v = fmaxf(v, dpp_f32(v, 3));
     return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
+// The same folds when only lanes 0 .. 15 hold anything (the rest 0.0 / -inf): the cross-row steps of wave_sum_f32 /
+// wave_max_f32 would add exact zeros (take the maximum with -inf) -- row 0 alone gives the same bits.
+__device__ __forceinline__ float row0_sum_f32(float v) {
+    v += dpp_f32(v, 0);
+    v += dpp_f32(v, 1);
+    v += dpp_f32(v, 2);
+    v += dpp_f32(v, 3);
+    return lane_f32(v, 0);
+}
+__device__ __forceinline__ float row0_max_f32(float v) {
+    v = fmaxf(v, dpp_f32(v, 0));
+    v = fmaxf(v, dpp_f32(v, 1));
+    v = fmaxf(v, dpp_f32(v, 2));
+    v = fmaxf(v, dpp_f32(v, 3));
+    return lane_f32(v, 0);
+}
 __device__ __forceinline__ float wave_sum_f32(float v) {
     v += dpp_f32(v, 0);
     v += dpp_f32(v, 1);
@@ -208,7 +224,7 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
     // (Until round 3 an fma chain in unit order: D dependent steps of two v_readlane each on the tail every game waits for.)
     const float sdv = lane < D ? fmaxf(__builtin_fmaf(R, d1k[lane], (float)HW * d1b[lane]), 0.f) : 0.f;
     const float d2kv = lane < D ? d2k[lane] : 0.f;
-    const float e = wave_sum_f32(sdv * d2kv) + d2b[0];
+    const float e = (D <= 16 ? row0_sum_f32(sdv * d2kv) : wave_sum_f32(sdv * d2kv)) + d2b[0];
     // tanh on the hardware exponential: 1 - 2 / (exp(2e) + 1) (v_exp_f32, v_rcp_f32: absolute error ~1e-7, the library tanhf is
     // ~60 instructions on the network wave's critical tail); saturates to +-1 through exp's overflow / underflow
     const float value = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(e * 2.88539008177792681472f) + 1.0f);
@@ -279,10 +295,11 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
         // pooled_sum -- the fixed pairwise tree the oracle restates (tree_sum64) -- not chains of A readlane steps.
         const bool act = lane < A;
         const float l = act ? wide_logit<HW>(R0, R1, pdk[act ? lane : 0], pdk[A + (act ? lane : 0)], pdb[act ? lane : 0]) : -INFINITY;
-        const float m = wave_max_f32(l);
+        constexpr bool ROW0 = A <= 16; // (every action on a lane of row 0)
+        const float m = ROW0 ? row0_max_f32(l) : wave_max_f32(l);
         float pr = act ? wide_expterm(l, m) : 0.f; // exp(l - m) on v_exp_f32, as the wide head does
-        const float tot = wave_sum_f32(pr);
-        pr = pr / tot;
+        const float tot = ROW0 ? row0_sum_f32(pr) : wave_sum_f32(pr);
+        pr = pr * __builtin_amdgcn_rcpf(tot); // (v_rcp_f32: one ulp; an IEEE division is twelve instructions on this tail, twice)
         if (noise) { // policy = (1-eps)*softmax + eps*Beta(alpha,1-alpha); policy /= sum(policy)   (NetworkFactory.py:176-182)
             // two lanes per action: lane pair (2a, 2a+1) tries Philox pairs k and k+1 side by side
             const float ia = nd.inv_alpha, ib = nd.inv_beta;
@@ -302,8 +319,8 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
             float nz = __shfl(r, 2 * (act ? lane : 0), 64); // action a's draw sits on lane 2a
             if (noise_ready) nz = act ? noise_ready[lane] : 0.f; // the same draws (bb_beta_noise: same trials in the same order), made ahead
             pr = (1.0f - nd.eps) * pr + nd.eps * (act ? nz : 0.f);
-            const float t2 = wave_sum_f32(pr);
-            pr = pr / t2;
+            const float t2 = ROW0 ? row0_sum_f32(pr) : wave_sum_f32(pr);
+            pr = pr * __builtin_amdgcn_rcpf(t2);
         }
         if (live && act && logits_out) logits_out[(size_t)pos * A + lane] = l;
         if (live && act && policy_out) policy_out[(size_t)pos * pstride + lane] = pr;
@@ -362,10 +379,10 @@ __device__ __forceinline__ float head_tree(const NetDev &nd, const float *hp, fl
         for (int a = 0; a < 16; a++) t[a] = a < A ? __shfl(v, base + a, 64) : 0.f;
         return tree16(t);
     };
-    pr = pr / gsum(pr);
+    pr = pr * __builtin_amdgcn_rcpf(gsum(pr));
     if (noise) {
         pr = (1.0f - nd.eps) * pr + nd.eps * (act ? nz : 0.f);
-        pr = pr / gsum(pr);
+        pr = pr * __builtin_amdgcn_rcpf(gsum(pr));
     }
     *prior_out = act ? pr : 0.f;
     return value;
