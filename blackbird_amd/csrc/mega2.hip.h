@@ -240,6 +240,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
 #endif
     if (threadIdx.x < MEGA2_QCAP) qc.q[threadIdx.x] = -1;
     for (int i = threadIdx.x; i < NETW * WAVE_F; i += MEGA2_THREADS) lds[i] = 0.f;
+    if (X3) for (int i = threadIdx.x; i < GW * S; i += MEGA2_THREADS) s_noise[i] = 0.f; // (the spare slot of a row is its ready flag)
     NetDev ndl = nd;
     NetX3 x3l = x3;
     {
@@ -492,6 +493,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
                     // the leaf's prior noise, drawn here (the same Philox trials in the same order as the network wave would make)
                     if constexpr (TREE_NOISE && !TREE_HEADS) // (with TREE_HEADS the draw is made when the evaluation is picked up: finish_eval)
                         if (noise_on && lane < A) s_noise[li * S + lane] = bb_beta_noise(ndl.seed, gid, (uint32_t)cur, (uint32_t)lane, ndl.alpha);
+                        if (noise_on && lane == 0) s_noise[li * S + S - 1] = 1.0f; // ready flag (head_one waits for it; here the draw precedes the post)
                     posting = true;
                     ph = PH_WAIT;
 #ifdef BB_STAMPS
@@ -589,14 +591,24 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
                     int used = __popcll(__ballot(ready && lane == 0));
                     if (l64 == 0) atomicSub(&wg_pool, used);
                 }
-                if constexpr (TREE_NOISE) {
-                    if (noise_on && ready && posted && lane < G::A)
-                        s_noise[li * S + lane] = bb_beta_noise(ndl.seed, d.leaf_game_id[g], (uint32_t)d.leaf_serial[g], (uint32_t)lane, ndl.alpha);
-                }
 #ifdef BB_STAMPS
                 if (ready && lane == 0 && posted) ts_post[li] = wall_clock64();
 #endif
+                // The leaf goes to the network waves FIRST; its prior noise (~1 k cycles of Philox + transcendentals) is drawn
+                // afterwards, while the evaluation runs: the network wave needs the draws only in its tail, ~30 k cycles later,
+                // and waits there for the flag in the game's spare noise slot (head_one) -- the draw is off the game's chain.
+                static_assert(!TREE_NOISE || G::A < S, "the noise flag sits in the lane group's spare slot");
+                uint32_t leaf_gid = 0u, leaf_ser = 0u;
+                if (TREE_NOISE && noise_on && ready && posted) { // (read before the push: the mailbox belongs to the network wave afterwards)
+                    leaf_gid = d.leaf_game_id[g];
+                    leaf_ser = (uint32_t)d.leaf_serial[g];
+                }
                 queue_push<NET_APPLIES>(&qc, &gstate[GSI(li < GW ? li : 0)], ready && lane == 0, posted, li);
+                if constexpr (TREE_NOISE) {
+                    if (noise_on && ready && posted && lane < G::A) s_noise[li * S + lane] = bb_beta_noise(ndl.seed, leaf_gid, leaf_ser, (uint32_t)lane, ndl.alpha);
+                    __threadfence_block();
+                    if (noise_on && ready && posted && lane == 0) __hip_atomic_store(&s_noise[li * S + S - 1], 1.0f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
 #ifdef BB_STAMPS
                 t_work += clock64() - ts;
 #endif

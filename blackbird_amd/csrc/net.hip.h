@@ -317,7 +317,16 @@ __device__ __forceinline__ void head_one(const NetDev &nd, float R, float R0, fl
             }
             r = r >= 0.0f ? r : nd.alpha;
             float nz = __shfl(r, 2 * (act ? lane : 0), 64); // action a's draw sits on lane 2a
-            if (noise_ready) nz = act ? noise_ready[lane] : 0.f; // the same draws (bb_beta_noise: same trials in the same order), made ahead
+            if (noise_ready) { // the same draws (bb_beta_noise: same trials in the same order), made by the tree wave that posted the leaf
+                // -- after it posted it (mega2.hip.h): wait for its flag in the spare slot of the game's noise row, take the draws,
+                // clear the flag for the game's next leaf.  (Bounded: a launch that is being aborted must still drain.)
+                float *nr = const_cast<float *>(noise_ready);
+                for (int spin = 0; spin < (1 << 16) && __hip_atomic_load(nr + G::S - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0.f; spin++)
+                    __builtin_amdgcn_s_sleep(1);
+                nz = act ? nr[lane] : 0.f;
+                wave_lds_handover();
+                if (lane == 0) __hip_atomic_store(nr + G::S - 1, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             pr = (1.0f - nd.eps) * pr + nd.eps * (act ? nz : 0.f);
             const float t2 = ROW0 ? row0_sum_f32(pr) : wave_sum_f32(pr);
             pr = pr * __builtin_amdgcn_rcpf(t2);
