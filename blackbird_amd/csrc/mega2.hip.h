@@ -297,6 +297,31 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
             }
             wave_lds_handover();
         };
+        // A leaf goes to the network waves the moment its mailbox is written (async_game's on_post hook) -- a call of this wave
+        // lasts as long as the slowest of its games' descents -- and its prior noise (~1 k cycles of Philox + transcendentals) is
+        // drawn right behind the queue entry, while the evaluation already runs: the network wave needs the draws only in its
+        // tail, ~30 k cycles later, and waits there for the flag in the game's spare noise slot (head_one).
+        static_assert(!TREE_NOISE || G::A < S, "the noise flag sits in the lane group's spare slot");
+        auto early_post = [&](int gg, int ln) __attribute__((always_inline)) {
+            if (NET_APPLIES) release_global_then_lds(); // mailbox (+ tree writes) before the queue entry
+            else __threadfence_block();
+            if (ln == 0) {
+#ifdef BB_STAMPS
+                ts_post[li] = wall_clock64();
+#endif
+                *(volatile uint8_t *)&gstate[GSI(li)] = 1;
+                const int idx = atomicAdd(&qc.tail, 1); // the entry becomes valid when its slot turns non-negative
+                *(volatile int *)&qc.q[idx & (MEGA2_QCAP - 1)] = li;
+            }
+            if constexpr (TREE_NOISE) {
+                if (noise_on) {
+                    if (ln < G::A) s_noise[li * S + ln] = bb_beta_noise(ndl.seed, d.leaf_game_id[gg], (uint32_t)d.leaf_serial[gg], (uint32_t)ln, ndl.alpha);
+                    __threadfence_block();
+                    if (ln == 0) __hip_atomic_store(&s_noise[li * S + S - 1], 1.0f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        };
+        (void)early_post;
         if constexpr (TREE_STEP) {
         // ---- level-stepped tree wave -----------------------------------------------------------------------------------------
         // The games of a wave do not take turns in whole async_game calls (apply -> descend to a leaf -> post; a result that
@@ -567,7 +592,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
 #ifdef BB_STAMPS_LIGHT
                 int ll = 0, lv = 0, lld = 0, lpu = 0;
                 if (ready) {
-                    posted = async_game<G, X3>(d, g, lane, ll, lv, lld, lpu);
+                    posted = async_game<G, X3>(d, g, lane, ll, lv, lld, lpu, early_post);
                     if (d.game_lid[g] < 0) alive = false;
                 }
                 { // the game with the most levels ran the whole length of the call: its loop time per level is undiluted
@@ -583,7 +608,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
                 }
 #else
                 if (ready) {
-                    posted = async_game<G, X3>(d, g, lane);
+                    posted = async_game<G, X3>(d, g, lane, early_post);
                     if (d.game_lid[g] < 0) alive = false; // slot ran out of games
                 }
 #endif
@@ -591,24 +616,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_selfplay_queue(TreeDev dg, NetDe
                     int used = __popcll(__ballot(ready && lane == 0));
                     if (l64 == 0) atomicSub(&wg_pool, used);
                 }
-#ifdef BB_STAMPS
-                if (ready && lane == 0 && posted) ts_post[li] = wall_clock64();
-#endif
-                // The leaf goes to the network waves FIRST; its prior noise (~1 k cycles of Philox + transcendentals) is drawn
-                // afterwards, while the evaluation runs: the network wave needs the draws only in its tail, ~30 k cycles later,
-                // and waits there for the flag in the game's spare noise slot (head_one) -- the draw is off the game's chain.
-                static_assert(!TREE_NOISE || G::A < S, "the noise flag sits in the lane group's spare slot");
-                uint32_t leaf_gid = 0u, leaf_ser = 0u;
-                if (TREE_NOISE && noise_on && ready && posted) { // (read before the push: the mailbox belongs to the network wave afterwards)
-                    leaf_gid = d.leaf_game_id[g];
-                    leaf_ser = (uint32_t)d.leaf_serial[g];
-                }
-                queue_push<NET_APPLIES>(&qc, &gstate[GSI(li < GW ? li : 0)], ready && lane == 0, posted, li);
-                if constexpr (TREE_NOISE) {
-                    if (noise_on && ready && posted && lane < G::A) s_noise[li * S + lane] = bb_beta_noise(ndl.seed, leaf_gid, leaf_ser, (uint32_t)lane, ndl.alpha);
-                    __threadfence_block();
-                    if (noise_on && ready && posted && lane == 0) __hip_atomic_store(&s_noise[li * S + S - 1], 1.0f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                // (posted leaves went to the network waves inside the call: early_post; the others go back to their tree wave)
+                queue_push<NET_APPLIES>(&qc, &gstate[GSI(li < GW ? li : 0)], ready && lane == 0 && !posted, false, li);
 #ifdef BB_STAMPS
                 t_work += clock64() - ts;
 #endif

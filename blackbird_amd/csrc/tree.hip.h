@@ -992,12 +992,18 @@ __global__ void __launch_bounds__(256) k_selfplay_move(TreeDev d) {
 // schedule (tests/test_gpu_mcts.py: self-play == oracle, example by example).
 // REC (persistent kernel with the recorded-path arrays in LDS): the descent notes N, W and sum(N) of every edge it takes and the
 // backups are stores only (backup_path_rec / phase_apply_rec).
-template <class G, bool REC = false>
+// on_post(g, lane): called by every lane of the game's group right after the leaf's mailbox has been written -- the persistent
+// kernel hands the leaf to its network waves THERE (mega2.hip.h), not when the call returns: a wave's call lasts as long as
+// the slowest of its games' descents.
+struct NoPostHook {
+    __device__ __forceinline__ void operator()(int, int) const {}
+};
+template <class G, bool REC = false, class OnPost = NoPostHook>
 __device__ bool async_game(const TreeDev &d, int g, int lane
 #ifdef BB_STAMPS_LIGHT
                            , int &g_light_loop, int &g_light_levels, int &g_light_load, int &g_light_puct
 #endif
-) {
+                           , OnPost on_post = OnPost()) {
     using Node = DenseNode<G>;
     constexpr int S = G::S, A = G::A;
     if (d.game_lid[g] < 0) return false;
@@ -1202,6 +1208,7 @@ __device__ bool async_game(const TreeDev &d, int g, int lane
             d.evals[g] += 1;
             d.ctr[(size_t)g * 8 + 6] += (uint64_t)((fl & F_OVERFLOW) ? 1 : 0);
         }
+        on_post(g, lane);
         sims_done++;
         depth_sum += depth;
         term_hits += (fl & F_TERM) ? 1 : 0;
