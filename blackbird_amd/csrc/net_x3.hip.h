@@ -250,7 +250,7 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
     }
     wave_lds_handover();
     NSUB(6);
-    if constexpr (!PP) {
+    if constexpr (!PP && WIDE_IN) { // (a 16-byte board is decoded from registers below; an 80-byte one through LDS)
         if (!planes && lane == 0) *sst = my_state;
         wave_lds_handover();
     }
@@ -294,7 +294,8 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             for (int c = 0; c < CIN; c++) v[c] = src[c];
         } else {
             int8_t e[CIN];
-            G::encode_cell(*sst_in, y, x, e);
+            if constexpr (PP) G::encode_cell(*sst_in, y, x, e);
+            else G::encode_cell(my_state, y, x, e); // (every lane holds the board: two 64-bit words)
 #pragma unroll
             for (int c = 0; c < CIN; c++) v[c] = e[c];
         }
