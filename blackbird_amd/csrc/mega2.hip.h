@@ -37,7 +37,7 @@
 #define BB_TREE_HEADS 0 // bf16-pipe network: 1 = the value / policy tails of an evaluation run on the tree wave that picks it up (net.hip.h head_tree)
 #endif
 #ifndef BB_TREE_NOISE
-#define BB_TREE_NOISE 1 // 1 = the prior noise of a posted leaf is drawn by its tree wave (also forced by BB_TREE_HEADS), 0 = by the network wave in head_one
+#define BB_TREE_NOISE 0 // 0 = the prior noise of a leaf is drawn by the network wave that evaluates it (head_one), 1 = by the tree wave that posted it, right behind the queue entry (also forced by BB_TREE_HEADS).  Round 2 chose 1: the tree waves had 20 % slack then; since the tree calls carry the posts (early_post) and the heads are short, the tree waves are the 93 % busy side: 0 measures +1.5 % (113.3 vs 111.6 M evaluations/s, eight alternations)
 #endif
 // Tree-wave schedule of the bf16-pipe kernel.  0 (default): a tree wave makes one async_game call at a time for those of its games
 // that are ready (apply -> descend to a leaf -> post).  1: level-stepped -- every iteration advances every descending game of the
