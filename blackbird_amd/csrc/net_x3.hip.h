@@ -239,10 +239,13 @@ __device__ __forceinline__ void net_body_x3(const NetDev &nd, const NetX3 &x3, i
             // after it); only the halo must read as zero: row 0, the first slot of rows 1 .. H, everything from row H + 1 on --
             // in both buffers, 16 bytes per lane and store
             constexpr int NHALO = RS + XG::H + (XG::SLOTS - (XG::H + 1) * RS), CH = SB / 16;
-            for (int i = lane; i < 2 * NHALO * CH; i += 64) {
+            constexpr int NCH = 2 * NHALO * CH;
+#pragma unroll
+            for (int k = 0; k < (NCH + 63) / 64; k++) { // (straight-line: a counted loop paid two branches and its index arithmetic per pass)
+                const int i = lane + 64 * k;
                 const int buf = i >= NHALO * CH, j = i - buf * NHALO * CH, hs = j / CH, c = j - hs * CH;
                 const int slot = hs < RS ? hs : hs < RS + XG::H ? (hs - RS + 1) * RS : (XG::H + 1) * RS + (hs - RS - XG::H);
-                *(u32x4 *)(wl + buf * XG::X_B + slot * SB + c * 16) = z;
+                if (64 * k + 63 < NCH || i < NCH) *(u32x4 *)(wl + buf * XG::X_B + slot * SB + c * 16) = z;
             }
         } else {
             for (int i = lane; i < XG::WAVE_BYTES / 16; i += 64) ((u32x4 *)wl)[i] = z;
